@@ -1,0 +1,219 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; ``balf_amd`` never does (the HIP path fails loudly instead of falling
+back here).
+
+A restatement, in plain torch/NumPy, of the BALF keypoint-detection hot path:
+
+* detector forward  -- /root/reference/balf/model/mlp_ma_decoder.py:223-285,
+  /root/reference/balf/model/decoder.py:16-30, /root/reference/balf/utils/tensor_op.py:15-27
+* pad / crop / border -- /root/reference/balf/utils/test_utils.py:16-47,
+  /root/reference/balf/utils/train_utils.py:437-442
+* window-max NMS      -- /root/reference/balf/utils/test_utils.py:50-54
+* K-th-threshold top-K -- /root/reference/balf/utils/test_utils.py:56-95,
+  /root/reference/balf/utils/train_utils.py:451-452
+
+Parity pinning: ``tests/golden/*.npz`` were produced by ``tests/golden/make_golden.py``,
+which imports the *reference itself* from /root/reference in the build container, loads
+the same seeded synthetic weights, and records its outputs.  ``tests/test_oracle_golden.py``
+checks every function here against those vectors (no GPU needed).  The arithmetic itself
+lives in third-party libraries the reference does not pin (torch, einops, scipy:
+requirements.txt:1,9,13); this file calls the same torch primitives for Linear /
+LayerNorm / GELU / softmax and re-derives the einops rearranges and SciPy's
+``maximum_filter`` by hand.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_RSH = "residual_split_head_multi_axis_gmlp_layer"
+_RCAB = "residual_channel_attention_block"
+
+
+# ----------------------------------------------------------------------------------------
+# detector forward
+# ----------------------------------------------------------------------------------------
+def _lin(sd, p, x):
+    return F.linear(x, sd[p + ".weight"], sd[p + ".bias"])
+
+
+def _ln(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def _gmlp_branch(sd, p, unit, z, grid: bool):
+    """GridGmlpLayer / BlockGmlpLayer (mlp_ma_decoder.py:57-70, 104-117) on NHWC ``z``.
+
+    The reference rearranges to [n, groups, tokens, c], mixes, and rearranges back; here the
+    64x64 token mix is applied in place on a 6-D view."""
+    n, h, w, c = z.shape
+    t = F.gelu(_lin(sd, p + ".dense1", _ln(sd, p + ".norm", z)))
+    a, b = t[..., :c], t[..., c:]
+    b = _ln(sd, f"{p}.{unit}.norm", b)
+    w4 = sd[f"{p}.{unit}.dense.weight"].reshape(8, 8, 8, 8)
+    b2 = sd[f"{p}.{unit}.dense.bias"].reshape(8, 8)
+    if grid:   # token = which of the 8x8 image regions; (iy, ix) inside the region is batch
+        b6 = b.reshape(n, 8, h // 8, 8, w // 8, c)                 # n gy iy gx ix c
+        mix = torch.einsum("pqgh,ngihjc->npiqjc", w4, b6) + b2[None, :, None, :, None, None]
+    else:      # token = position inside each contiguous 8x8 block
+        b6 = b.reshape(n, h // 8, 8, w // 8, 8, c)                 # n by iy bx ix c
+        mix = torch.einsum("pqgh,nygxhc->nypxqc", w4, b6) + b2[None, None, :, None, :, None]
+    mix = mix.reshape(n, h, w, c)
+    return z + _lin(sd, p + ".dense2", a * (mix + 1.0))
+
+
+def stage_forward(sd: Dict[str, torch.Tensor], d: str, x_nhwc: torch.Tensor, last: bool,
+                  taps: Dict[str, torch.Tensor] = None) -> torch.Tensor:
+    """One ``Down`` stage (mlp_ma_decoder.py:223-244) on NHWC input, NHWC output."""
+    c = sd[f"{d}.conv.0.weight"].shape[0]
+    x0 = F.relu(_lin(sd, f"{d}.conv.0", x_nhwc))
+    q = f"{d}.{_RSH}"
+    y = F.gelu(_lin(sd, q + ".dense1", _ln(sd, q + ".norm", x0)))
+    u, v = y[..., :c], y[..., c:]
+    u = _gmlp_branch(sd, q + ".grid_gmlp_layer", "grid_gating_unit", u, True)
+    v = _gmlp_branch(sd, q + ".block_gmlp_layer", "block_gating_unit", v, False)
+    x1 = _lin(sd, q + ".dense2", torch.cat([u, v], dim=-1)) + x0
+    r = f"{d}.{_RCAB}"
+    t = _lin(sd, r + ".conv2", F.leaky_relu(_lin(sd, r + ".conv1", _ln(sd, r + ".norm", x1)), 0.2))
+    m = t.mean(dim=(1, 2))                                          # CALayer squeeze (:166)
+    s = torch.sigmoid(_lin(sd, r + ".calayer.excite.2", F.relu(_lin(sd, r + ".calayer.excite.0", m))))
+    x2 = t * s[:, None, None, :] + x1 + x0
+    if taps is not None:
+        taps[d + ".u"], taps[d + ".x1"], taps[d + ".t"], taps[d + ".s"], taps[d + ".x2"] = u, x1, t, s, x2
+    if last:
+        return _lin(sd, f"{d}.conv2", x2)
+    n, h, w, _ = x2.shape
+    return x2.reshape(n, h // 2, 2, w // 2, 2, c).amax(dim=(2, 4))   # MaxPool2d(2) (:219,236)
+
+
+def detector_forward(sd: Dict[str, torch.Tensor], x_nchw: torch.Tensor,
+                     taps: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """``MLP_MA_DECODER.forward`` (mlp_ma_decoder.py:278-285): NCHW float input with H, W
+    multiples of 64 -> {'logits': [B,65,H/8,W/8], 'prob': [B,H,W]}.  Computes in the dtype of
+    ``x_nchw``/``sd`` (fp32 to match the reference, fp64 for a tighter yardstick)."""
+    if x_nchw.shape[-1] % 64 or x_nchw.shape[-2] % 64:
+        raise ValueError("H and W must be multiples of 64")
+    x = x_nchw.permute(0, 2, 3, 1)
+    for i in range(4):
+        x = stage_forward(sd, f"down{i + 1}", x, last=(i == 3), taps=taps)
+    z = _lin(sd, "detector_head.dense", F.relu(x))
+    hp = "detector_head.norm."
+    z = (z - sd[hp + "running_mean"]) / torch.sqrt(sd[hp + "running_var"] + 1e-5) * sd[hp + "weight"] + sd[hp + "bias"]
+    p = torch.softmax(z, dim=-1)[..., :64]                          # drop dustbin (decoder.py:25)
+    n, h, w, _ = p.shape
+    prob = p.reshape(n, h, w, 8, 8).permute(0, 1, 3, 2, 4).reshape(n, h * 8, w * 8)
+    return {"logits": z.permute(0, 3, 1, 2).contiguous(), "prob": prob.contiguous()}
+
+
+def cast_state(sd: Dict[str, torch.Tensor], dtype) -> Dict[str, torch.Tensor]:
+    return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------------------
+# pre / post processing (NumPy)
+# ----------------------------------------------------------------------------------------
+def make_shape_even(image: np.ndarray) -> np.ndarray:
+    h, w = image.shape[:2]
+    return np.pad(image, ((0, h & 1), (0, w & 1), (0, 0)), mode="constant")
+
+
+def mod_padding_symmetric(image: np.ndarray, factor: int = 64) -> np.ndarray:
+    h, w = image.shape[:2]
+    ph = ((h + factor) // factor) * factor - h if h % factor else 0
+    pw = ((w + factor) // factor) * factor - w if w % factor else 0
+    return np.pad(image, ((ph // 2, ph // 2), (pw // 2, pw // 2), (0, 0)), mode="constant")
+
+
+def crop_offsets(h: int, w: int, hp: int, wp: int) -> Tuple[int, int]:
+    he, we = h + (h & 1), w + (w & 1)
+    return hp // 2 - he // 2, wp // 2 - we // 2
+
+
+def remove_borders(score: np.ndarray, b: int) -> np.ndarray:
+    out = np.zeros_like(score)
+    h, w = score.shape[:2]
+    out[b:h - b, b:w - b] = score[b:h - b, b:w - b]
+    return out
+
+
+def window_max(score: np.ndarray, size: int) -> np.ndarray:
+    """Clipped-window maximum over rows/cols [i - size//2, i + (size-1)//2]: what SciPy's
+    ``maximum_filter(footprint=ones((size,size)))`` with its default ``mode='reflect'``
+    computes (reflected samples always lie inside the clipped window)."""
+    lo, hi = size // 2, (size - 1) // 2
+    h, w = score.shape
+    neg = np.array(-np.inf, dtype=score.dtype)
+    p = np.pad(score, ((lo, hi), (0, 0)), mode="constant", constant_values=neg)
+    m = p[0:h]
+    for k in range(1, size):
+        m = np.maximum(m, p[k:k + h])
+    p = np.pad(m, ((0, 0), (lo, hi)), mode="constant", constant_values=neg)
+    m2 = p[:, 0:w]
+    for k in range(1, size):
+        m2 = np.maximum(m2, p[:, k:k + w])
+    return m2
+
+
+def apply_nms(score: np.ndarray, size: int) -> np.ndarray:
+    return score * (score == window_max(score, size))
+
+
+def topk_threshold(nms: np.ndarray, k: int) -> float:
+    """K-th largest value of the whole map with the reference's fallback when it is <= 0
+    (test_utils.py:78-89).  ``k > nms.size`` is an IndexError there and here."""
+    flat = nms.ravel()
+    if k > flat.size:
+        raise IndexError("num_points exceeds the number of pixels")
+    thr = np.partition(flat, flat.size - k)[flat.size - k]
+    if thr <= 0.0:
+        pos = flat[flat > 0.0]
+        thr = pos.min() if pos.size else flat.dtype.type(0.0)
+    return thr
+
+
+def select_topk(nms: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Flat indices (row-major, ascending) and scores of the first ``k`` pixels in raster order
+    with ``nms >= thr`` (test_utils.py:93-95)."""
+    thr = topk_threshold(nms, k)
+    idx = np.flatnonzero(nms.ravel() >= thr)[:k]
+    return idx.astype(np.int64), nms.ravel()[idx]
+
+
+def canonical_order(idx: np.ndarray, score: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Score descending, flat index ascending among equal scores.  The reference's final
+    ``argsort(-score)`` (train_utils.py:451) leaves the order of equal scores unspecified;
+    this is the canonical representative the HIP path emits."""
+    o = np.lexsort((idx, -score.astype(np.float64)))
+    return idx[o], score[o]
+
+
+def detect_from_prob(prob_pad: np.ndarray, h: int, w: int, border: int, nms_size: int, k: int):
+    """crop -> remove_borders -> apply_nms -> top-K on one padded score map
+    (train_utils.py:437-452).  Returns canonical (idx, score)."""
+    top, left = crop_offsets(h, w, *prob_pad.shape)
+    score = remove_borders(prob_pad[top:top + h, left:left + w], border)
+    idx, sc = select_topk(apply_nms(score, nms_size), k)
+    return canonical_order(idx, sc)
+
+
+def points_xysr(idx: np.ndarray, score: np.ndarray, w: int) -> np.ndarray:
+    """Rows ``[x, y, 1.0, score]`` float64, the reference's 'xysr' layout (test_utils.py:63-64)."""
+    out = np.empty((idx.size, 4), dtype=np.float64)
+    out[:, 0], out[:, 1], out[:, 2], out[:, 3] = idx % w, idx // w, 1.0, score
+    return out
+
+
+def extract_detections(sd, image_rgb_norm: np.ndarray, nms_size=15, num_points=25, border_size=15):
+    """Whole single-image pipeline (train_utils.py:416-454) on the CPU."""
+    h, w = image_rgb_norm.shape[:2]
+    pad = mod_padding_symmetric(make_shape_even(image_rgb_norm), 64)
+    x = torch.tensor(pad, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0)
+    with torch.no_grad():
+        prob = detector_forward(sd, x)["prob"][0].numpy()
+    idx, sc = detect_from_prob(prob, h, w, border_size, nms_size, num_points)
+    return points_xysr(idx, sc, w), prob

@@ -1,0 +1,79 @@
+"""Case tables shared by make_golden.py (which runs the reference) and the tests (which run the
+oracle / the HIP path).  Inputs are regenerated from seeds on both sides; only the reference's
+outputs are stored in the .npz fixtures."""
+import numpy as np
+import torch
+
+WEIGHT_SEED = 20240
+
+# name -> (batch, H, W, input seed)         H, W multiples of 64
+FORWARD_SMALL = {
+    "b2_64x64": (2, 64, 64, 11),
+    "b1_128x192": (1, 128, 192, 12),
+    "b1_256x320": (1, 256, 320, 13),
+}
+TAP_CASE = "b2_64x64"
+
+# name -> (h, w, K, synthetic image index)  un-padded image sizes, run through pad/crop
+FORWARD_CFG = {
+    "vga": (480, 640, 1000, 0),
+}
+
+
+def CFG_ROWS(hp):
+    return np.array([0, 1, hp // 3, hp // 2, hp - 2, hp - 1])
+
+
+def forward_input(b, h, w, seed):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.random((b, 3, h, w), dtype=np.float32))
+
+
+# NMS / top-K cases on synthetic score maps
+NMS_CASES = {
+    "rand_120x160":     dict(h=120, w=160, seed=1, kind="rand", border=15, nms=15, k=100),
+    "rand_480x640":     dict(h=480, w=640, seed=2, kind="rand", border=15, nms=15, k=1000),
+    "ties_480x640":     dict(h=480, w=640, seed=3, kind="quant", border=15, nms=15, k=1000),
+    "ties_coarse":      dict(h=200, w=333, seed=4, kind="quant8", border=15, nms=15, k=500),
+    "zeros_96x128":     dict(h=96, w=128, seed=5, kind="zeros", border=15, nms=15, k=50),
+    "sparse_few":       dict(h=150, w=170, seed=6, kind="sparse", border=15, nms=15, k=400),
+    "const_plateau":    dict(h=90, w=110, seed=7, kind="const", border=15, nms=15, k=300),
+    "nms3_odd":         dict(h=101, w=77, seed=8, kind="rand", border=0, nms=3, k=200),
+    "nms4_even":        dict(h=64, w=96, seed=9, kind="quant8", border=2, nms=4, k=150),
+    "nms16_even":       dict(h=128, w=128, seed=10, kind="rand", border=15, nms=16, k=64),
+    "nms5_border1":     dict(h=70, w=70, seed=11, kind="quant", border=1, nms=5, k=4000),
+    "rand_720p":        dict(h=720, w=1280, seed=12, kind="rand", border=15, nms=15, k=2000),
+    "blobs_1080p":      dict(h=1080, w=1920, seed=13, kind="blobs", border=15, nms=15, k=2000),
+    "k_eq_1":           dict(h=80, w=90, seed=14, kind="rand", border=15, nms=15, k=1),
+    "thin_border_all":  dict(h=40, w=200, seed=15, kind="rand", border=20, nms=15, k=10),
+}
+
+
+def nms_input(spec):
+    h, w, kind = spec["h"], spec["w"], spec["kind"]
+    rng = np.random.default_rng(1000 + spec["seed"])
+    if kind == "rand":
+        return rng.random((h, w), dtype=np.float32)
+    if kind == "quant":
+        return (np.round(rng.random((h, w), dtype=np.float32) * 200.0) / 200.0).astype(np.float32)
+    if kind == "quant8":
+        return (np.round(rng.random((h, w), dtype=np.float32) * 8.0) / 8.0).astype(np.float32)
+    if kind == "zeros":
+        return np.zeros((h, w), np.float32)
+    if kind == "const":
+        return np.full((h, w), 0.25, np.float32)
+    if kind == "sparse":
+        m = np.zeros((h, w), np.float32)
+        n = 60
+        ys, xs = rng.integers(0, h, n), rng.integers(0, w, n)
+        m[ys, xs] = rng.random(n, dtype=np.float32) + 0.01
+        return m
+    if kind == "blobs":      # smooth map, softmax-like dynamic range
+        g = rng.random((h // 4 + 2, w // 4 + 2), dtype=np.float32)
+        up = np.kron(g, np.ones((4, 4), np.float32))[:h, :w]
+        noise = rng.random((h, w), dtype=np.float32) * 0.05
+        return (np.exp(4.0 * up + noise) / np.exp(4.05) * 0.3).astype(np.float32)
+    raise ValueError(kind)
+
+
+PAD_SIZES = [(480, 640), (720, 1280), (1080, 1920), (481, 641), (64, 64), (100, 130), (511, 512), (65, 1)]

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE itself.
+
+Run in the build container only (the reference is mounted read-only at /root/reference
+and never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+What is recorded is data only -- inputs are regenerated from seeds, outputs are arrays:
+  forward_small.npz   logits/prob (+ per-stage outputs) of the reference model with the
+                      seeded synthetic weights of balf_amd.utils.synth on small inputs
+  forward_cfg.npz     strided prob samples + reference top-K index lists at 512x640
+  nms_topk.npz        remove_borders/apply_nms/find_index_higher_scores results on synthetic
+                      score maps (random, tie-heavy, all-zero, sparse, even window sizes)
+  geometry.json       pad/crop shapes+offsets, state-dict table, checkpoint-loader behaviour
+"""
+import json
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(1, "/root/reference")
+warnings.filterwarnings("ignore")
+
+from balf.model import get_model as ref_get_model          # noqa: E402  (reference)
+from balf.utils import test_utils as RT                     # noqa: E402  (reference)
+
+from balf_amd.utils import synth                            # noqa: E402
+from tests.golden import cases                              # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def ref_model(seed):
+    cfg = RT.get_cfg_from_yaml_file("/root/reference/balf/configs/test.yaml")
+    m = ref_get_model.load_model(cfg["model"]).eval()
+    sd = synth.synthetic_state_dict(seed)
+    assert list(sd.keys()) == list(m.state_dict().keys())
+    m.load_state_dict(sd)
+    return m, cfg
+
+
+def ref_detect(score_pad, h, w, border, nms_size, k):
+    """The glue of train_utils.extract_detections:437-452 around the reference's own functions."""
+    hp, wp = score_pad.shape
+    he, we = h + (h & 1), w + (w & 1)
+    hs, ws = hp // 2 - he // 2, wp // 2 - we // 2
+    score = score_pad[hs:hs + h, ws:ws + w]
+    nms = RT.apply_nms(RT.remove_borders(score, borders=border), nms_size)
+    pts = RT.get_point_coordinates(nms, num_points=k, order_coord="xysr")
+    if pts.size == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.float32)
+    idx = (pts[:, 1].astype(np.int64) * w + pts[:, 0].astype(np.int64))
+    sc = pts[:, 3].astype(np.float32)
+    o = np.argsort(idx)
+    return idx[o], sc[o]
+
+
+def main():
+    out = {}
+    # ---------------- forward, small ----------------
+    m, cfg = ref_model(cases.WEIGHT_SEED)
+    fw = {}
+    for name, (b, h, w, seed) in cases.FORWARD_SMALL.items():
+        x = cases.forward_input(b, h, w, seed)
+        stage_out = {}
+        hooks = []
+        if name == cases.TAP_CASE:
+            for s in ("down1", "down2", "down3", "down4"):
+                hooks.append(getattr(m, s).register_forward_hook(
+                    lambda mod, i, o, s=s: stage_out.__setitem__(s, o.detach().numpy().copy())))
+        with torch.inference_mode():
+            o = m(x)
+        for hk in hooks:
+            hk.remove()
+        fw[name + ".logits"] = o["logits"].numpy()
+        fw[name + ".prob"] = o["prob"].numpy()
+        for s, v in stage_out.items():
+            fw[f"{name}.{s}"] = v          # NCHW, as the reference's Down returns it
+    np.savez_compressed(os.path.join(HERE, "forward_small.npz"), **fw)
+
+    # ---------------- forward at a config size (strided samples + detections) ----------------
+    fc = {}
+    for name, (h, w, k, img_index) in cases.FORWARD_CFG.items():
+        img = synth.gray_to_rgb_norm(synth.synthetic_gray_u8(h, w, img_index))
+        pad = RT.mod_padding_symmetric(RT.make_shape_even(img), factor=64)
+        x = torch.tensor(pad, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0)
+        with torch.inference_mode():
+            prob = m(x)["prob"][0].numpy()
+        fc[name + ".prob_s8"] = prob[::8, ::8].copy()
+        fc[name + ".prob_rows"] = prob[cases.CFG_ROWS(prob.shape[0])].copy()
+        idx, sc = ref_detect(prob, h, w, 15, 15, k)
+        fc[name + ".idx"] = idx.astype(np.int32)
+        fc[name + ".score"] = sc
+    np.savez_compressed(os.path.join(HERE, "forward_cfg.npz"), **fc)
+
+    # ---------------- NMS / top-K on synthetic score maps ----------------
+    nk = {}
+    for name, spec in cases.NMS_CASES.items():
+        score = cases.nms_input(spec)
+        h, w = score.shape
+        rb = RT.remove_borders(score, borders=spec["border"])
+        nms = RT.apply_nms(rb, spec["nms"])
+        nk[name + ".nms_nonzero"] = np.flatnonzero(nms.ravel() != 0).astype(np.int32)
+        idxs = RT.find_index_higher_scores(nms, num_points=spec["k"])
+        flat = (idxs[:, 0].astype(np.int64) * w + idxs[:, 1]).astype(np.int32)
+        nk[name + ".idx"] = flat                       # raster order, as argwhere returns it
+        nk[name + ".score"] = nms.ravel()[flat].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "nms_topk.npz"), **nk)
+
+    # ---------------- geometry, state-dict table, loader behaviour ----------------
+    geo = {"pad": {}, "state": [], "loader": {}}
+    for (h, w) in cases.PAD_SIZES:
+        img = np.zeros((h, w, 3))
+        ev = RT.make_shape_even(img)
+        pd = RT.mod_padding_symmetric(ev, factor=64)
+        hp, wp = pd.shape[:2]
+        # where the original image's (0,0) lands in the padded array
+        probe = np.zeros((h, w, 3)); probe[0, 0, 0] = 1.0
+        pp = RT.mod_padding_symmetric(RT.make_shape_even(probe), factor=64)
+        y0, x0 = np.argwhere(pp[:, :, 0] == 1.0)[0]
+        geo["pad"][f"{h}x{w}"] = {"even": list(ev.shape[:2]), "padded": [hp, wp], "origin": [int(y0), int(x0)],
+                                   "h_start": hp // 2 - ev.shape[0] // 2, "w_start": wp // 2 - ev.shape[1] // 2}
+    geo["state"] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+
+    with tempfile.TemporaryDirectory() as td:
+        sd = synth.synthetic_state_dict(7)
+        full = os.path.join(td, "full.pth")
+        torch.save({"epoch": 12, "repeatability": 0.5, "model_state": sd, "optimizer_state": None}, full)
+        m2, _ = ref_model(0)
+        geo["loader"]["full"] = list(ref_get_model.load_test_pretrained_model(m2, full, device="cpu"))
+        geo["loader"]["full_probe"] = float(m2.state_dict()["down3.conv2.bias"][5])
+        bare = os.path.join(td, "bare.pth")
+        torch.save({"model_state": sd}, bare)
+        geo["loader"]["bare"] = list(ref_get_model.load_test_pretrained_model(m2, bare, device="cpu"))
+        for tag, mut in (("missing_key", lambda d: d.pop("down2.conv2.bias")),
+                         ("wrong_shape", lambda d: d.__setitem__("down1.conv.0.weight", torch.zeros(32, 4))),
+                         ("extra_key", lambda d: d.__setitem__("not.a.key", torch.zeros(1)))):
+            d = dict(sd); mut(d)
+            p = os.path.join(td, tag + ".pth")
+            torch.save({"model_state": d}, p)
+            try:
+                ref_get_model.load_test_pretrained_model(m2, p, device="cpu")
+                geo["loader"][tag] = "ok"
+            except AssertionError:
+                geo["loader"][tag] = "AssertionError"
+        try:
+            ref_get_model.load_test_pretrained_model(m2, os.path.join(td, "nope.pth"), device="cpu")
+            geo["loader"]["missing_file"] = "ok"
+        except FileNotFoundError:
+            geo["loader"]["missing_file"] = "FileNotFoundError"
+    geo["versions"] = {"torch": torch.__version__, "numpy": np.__version__}
+    with open(os.path.join(HERE, "geometry.json"), "w") as f:
+        json.dump(geo, f, indent=1)
+    for fn in sorted(os.listdir(HERE)):
+        print(fn, os.path.getsize(os.path.join(HERE, fn)))
+
+
+if __name__ == "__main__":
+    main()
