@@ -1,0 +1,77 @@
+"""ctypes binding of libbalf_hip.so (include/balf_hip.h).
+
+There is no CPU fallback anywhere in ``balf_amd``: if the shared library is missing or the
+device is not an MI355X, the calls below raise.  The library is built in-tree by
+``balf_amd/csrc/build.sh`` (plain ``hipcc --offload-arch=gfx950``, see ``__graft_entry__.build``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbalf_hip.so")
+
+OK = 0
+PREC_FP32, PREC_FP16 = 0, 1
+MAX_NMS_SIZE, MAX_TOPK = 32, 16384
+
+# name -> (restype, argtypes); kept in step with include/balf_hip.h (tests/test_abi.py checks)
+_vp, _i, _sz, _fp = C.c_void_p, C.c_int, C.c_size_t, C.c_void_p
+PROTOTYPES = {
+    "balf_abi_version": (_i, []),
+    "balf_error_string": (C.c_char_p, [_i]),
+    "balf_device_check": (_i, []),
+    "balf_num_state_tensors": (_i, []),
+    "balf_state_tensor_name": (C.c_char_p, [_i]),
+    "balf_state_tensor_numel": (_sz, [_i]),
+    "balf_packed_weights_bytes": (_sz, [_i]),
+    "balf_pack_weights": (_i, [C.POINTER(_vp), _i, _i, _vp, _sz]),
+    "balf_forward_workspace_bytes": (_sz, [_i, _i, _i]),
+    "balf_forward": (_i, [_vp, _i, _fp, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
+    "balf_window_nms": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp]),
+    "balf_nms_topk_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "balf_nms_topk": (_i, [_fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _fp, _vp, _vp, _sz, _vp]),
+}
+
+
+class BalfHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the library once; fail loudly when it is absent (never fall back to a CPU path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise BalfHipError(
+                f"{LIB_PATH} not found: build it with balf_amd/csrc/build.sh (or __graft_entry__.build()); "
+                "balf_amd has no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if l.balf_abi_version() != 1:
+            raise BalfHipError("libbalf_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != OK:
+        raise BalfHipError(f"{what} failed: {lib().balf_error_string(rc).decode()} ({rc})")
+
+
+def require_gpu_tensor(t, name: str) -> None:
+    if not t.is_cuda:
+        raise BalfHipError(f"{name} must live on the GPU: balf_amd has no CPU path (got device {t.device})")
+    if not t.is_contiguous():
+        raise BalfHipError(f"{name} must be contiguous")
+
+
+def current_stream_ptr(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,664 @@
+// BALF detector forward on gfx950: fp32 path on v_mfma_f32_16x16x4_f32 (exact fp32 fma chains).
+//
+// Replaces MLP_MA_DECODER.forward (/root/reference/balf/model/mlp_ma_decoder.py:278-285): four Down
+// stages (:223-244) of the multi-axis gated MLP (:132-149, :57-70, :104-117, :36-42, :83-89) with
+// the residual channel-attention block (:185-199, :166-171), then DetectorHead.forward
+// (/root/reference/balf/model/decoder.py:16-30) with pixel_shuffle
+// (/root/reference/balf/utils/tensor_op.py:15-27).
+//
+// Design ("pixel on the lane"): every Linear is computed transposed, D[out_ch][pixel] = W * act^T, so
+// the MFMA accumulator leaves a pixel in lane&15 and its channels 16*t + 4*(lane>>4) + r in register
+// r of tile t -- exactly the B-operand layout of the next Linear.  A wave therefore owns 16*P pixels
+// and carries them through a whole chain of Linear / LayerNorm / GELU layers in registers; LayerNorm is
+// a per-lane register reduction plus two cross-quarter exchanges.  Chained inputs are parked in a
+// wave-private LDS slot only so that the K loop can be a runtime loop (small code) -- no barrier.
+// The only cross-wave step is the 64x64 token mix (a sum over pixels = over lanes): its operand is
+// transposed through LDS ([channel][token]) and consumed as the MFMA A operand.
+//
+// Kernels per stage:
+//   stage_branch_kernel<.., MODE=0>  64-pixel groups = the 8x8 grid cells at one in-cell offset:
+//        x0 = relu(conv0 X) -> LN -> dense1[:C] -> GELU = u -> grid gMLP -> u'   (written to HBM)
+//   stage_branch_kernel<.., MODE=1>  64-pixel groups = 8x8 blocks:
+//        x0 -> LN -> dense1[C:] -> GELU = v -> block gMLP -> v';  x1 = dense2(cat[u', v']) + x0;
+//        t = conv2(lrelu(conv1(LN x1)));  writes t, r = x1 + x0 and per-workgroup channel sums of t
+//   se_kernel        per image: mean(t) -> C/4 -> C MLP -> sigmoid                (deterministic order)
+//   pool_kernel      stages 1-3: x2 = t*s + r, 2x2 max pool -> next stage's NHWC input
+//   head_kernel      stage 4: x2 -> conv2 -> relu -> dense(256->65) -> BN -> softmax -> pixel shuffle
+#include "common.h"
+#include "layout.h"
+
+namespace {
+
+using namespace balf;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f4 ldg4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+
+template <int C> struct StageP;               // pixel tiles (of 16) per wave
+template <> struct StageP<32> { static constexpr int P = 4; };
+template <> struct StageP<64> { static constexpr int P = 2; };
+template <> struct StageP<128> { static constexpr int P = 1; };
+template <> struct StageP<256> { static constexpr int P = 1; };
+
+constexpr int kBtPitch = kTokens + 4;          // floats per channel row of the transposed token tile
+
+// ------------------------------------------------------------------------------------------------
+// register-tile helpers: a [C]-channel activation of 16*P pixels is f4 t[NT][P], NT = C/16
+// ------------------------------------------------------------------------------------------------
+template <int NT, int P>
+__device__ __forceinline__ void init_bias(f4 (&t)[NT][P], const float *bias, int q) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const f4 b = ldg4(bias + 16 * nt + 4 * q);
+#pragma unroll
+        for (int p = 0; p < P; ++p) t[nt][p] = b;
+    }
+}
+
+__device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int NT, int P>
+__device__ __forceinline__ void gelu(f4 (&t)[NT][P]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[nt][p][r] = gelu1(t[nt][p][r]);
+}
+
+template <int NT, int P>
+__device__ __forceinline__ void relu(f4 (&t)[NT][P]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[nt][p][r] = fmaxf(t[nt][p][r], 0.0f);
+}
+
+template <int NT, int P>
+__device__ __forceinline__ void lrelu(f4 (&t)[NT][P]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = t[nt][p][r];
+                t[nt][p][r] = v > 0.0f ? v : 0.2f * v;
+            }
+}
+
+__device__ __forceinline__ float quarter_allreduce(float v) {   // the 4 lanes l, l^16, l^32, l^48
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// LayerNorm over the channel axis (eps 1e-5, affine), y may alias x.
+template <int NT, int P>
+__device__ __forceinline__ void layernorm(const f4 (&x)[NT][P], f4 (&y)[NT][P], const float *g, const float *b,
+                                          int q) {
+    constexpr float inv_c = 1.0f / (16 * NT);
+    float mean[P], rstd[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        float s = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) s += (x[nt][p][0] + x[nt][p][1]) + (x[nt][p][2] + x[nt][p][3]);
+        mean[p] = quarter_allreduce(s) * inv_c;
+        float v = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = x[nt][p][r] - mean[p];
+                v += d * d;
+            }
+        rstd[p] = 1.0f / sqrtf(quarter_allreduce(v) * inv_c + kLnEps);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const f4 gg = ldg4(g + 16 * nt + 4 * q), bb = ldg4(b + 16 * nt + 4 * q);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[nt][p][r] = (x[nt][p][r] - mean[p]) * rstd[p] * gg[r] + bb[r];
+    }
+}
+
+template <int NT, int P>
+__device__ __forceinline__ void store_slot(f4 *slot, const f4 (&t)[NT][P], int lane) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) slot[(nt * P + p) * 64 + lane] = t[nt][p];
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM: acc[NT0 .. NT0+NTC)[P] += W[rows of weight tiles wnt0.. , K range kt0..kt0+ktn) * in
+//   wf    : fragment-ordered weights (layout.h), KTtot = K/16 tiles per weight row-tile
+//   bload : (kk, p) -> f4 holding input channels 16*(kt0'+kk) + 4*q + {0..3} of pixel tile p
+// The kt loop is a runtime loop; the next step's weight fragments are prefetched into registers.
+// ------------------------------------------------------------------------------------------------
+template <int NTT, int NT0, int NTC, int P, typename BL>
+__device__ __forceinline__ void gemm_chunk(f4 (&acc)[NTT][P], const f4 *__restrict__ wf, int wnt0, int KTtot,
+                                           int kt0, int ktn, int lane, BL bload) {
+    const f4 *wp = wf + ((size_t)(wnt0 + NT0) * KTtot + kt0) * 64 + lane;
+    const int nstride = KTtot * 64;
+    f4 a[NTC];
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) a[nt] = wp[nt * nstride];
+#pragma unroll 2
+    for (int kk = 0; kk < ktn; ++kk) {
+        f4 an[NTC];
+        const int kn = (kk + 1 < ktn) ? (kk + 1) : kk;
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) an[nt] = wp[nt * nstride + kn * 64];
+        f4 b[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) b[p] = bload(kk, p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[NT0 + nt][p] = mfma4(a[nt][j], b[p][j], acc[NT0 + nt][p]);
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) a[nt] = an[nt];
+    }
+}
+
+template <int NTT, int NT0, int CH, int P, typename BL>
+__device__ __forceinline__ void gemm_from(f4 (&acc)[NTT][P], const f4 *__restrict__ wf, int wnt0, int KTtot, int kt0,
+                                          int ktn, int lane, BL bload) {
+    if constexpr (NT0 < NTT) {
+        constexpr int NTC = (NTT - NT0) < CH ? (NTT - NT0) : CH;
+        gemm_chunk<NTT, NT0, NTC, P>(acc, wf, wnt0, KTtot, kt0, ktn, lane, bload);
+        gemm_from<NTT, NT0 + NTC, CH, P>(acc, wf, wnt0, KTtot, kt0, ktn, lane, bload);
+    }
+}
+
+// all NTT output tiles, in chunks of CH weight row-tiles (bounds the live weight fragments)
+template <int NTT, int P, typename BL>
+__device__ __forceinline__ void gemm(f4 (&acc)[NTT][P], const float *w, int wnt0, int KTtot, int kt0, int ktn,
+                                     int lane, BL bload) {
+    constexpr int CH = (P >= 4) ? 2 : (P == 2 ? 4 : 8);
+    gemm_from<NTT, 0, CH, P>(acc, reinterpret_cast<const f4 *>(w), wnt0, KTtot, kt0, ktn, lane, bload);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct StageArgs {
+    const float *blob;
+    StageOff off;
+    const float *X;       // stage input: NCHW [B,3,H,W] (stage 1) or NHWC [B,H,W,CIN]
+    int B, H, W;          // resolution of this stage
+    float *U;             // [B,H,W,C] grid-branch output u'
+    float *T;             // [B,H,W,C] RCAB body output t
+    float *R;             // [B,H,W,C] x1 + x0
+    float *partial;       // [B, wgs_per_image, C] channel sums of t
+};
+
+template <int C, int P>
+constexpr int stage_lds_bytes() {
+    constexpr int slots = 4 * (C / 16) * P * 1024;
+    constexpr int bt = P * C * kBtPitch * 4;
+    return (slots > bt ? slots : bt) + 4 * C * 4;
+}
+
+template <int C, int CIN, int MODE>
+__global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel(StageArgs A) {
+    constexpr int P = StageP<C>::P;
+    constexpr int NT = C / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f4 *smem = reinterpret_cast<f4 *>(smem_raw);
+    float *bT = reinterpret_cast<float *>(smem_raw);
+    constexpr int main_bytes = stage_lds_bytes<C, P>() - 4 * C * 4;
+    float *red = reinterpret_cast<float *>(smem_raw + main_bytes);                    // [4][C]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, li = lane & 15;
+    f4 *slot = smem + wave * (NT * P * 64);
+    const float *blob = A.blob;
+    const StageOff &S = A.off;
+    const BranchOff &Br = S.br[MODE];
+
+    // ---- which 64-pixel groups does this workgroup own, and which pixel is this lane's ----
+    const int H = A.H, W = A.W;
+    const int cols = W / 8 / P;                       // work items per row of items
+    const int per_img = (H / 8) * cols;
+    const int n = blockIdx.x / per_img;
+    const int rem = blockIdx.x - n * per_img;
+    const int iy0 = rem / cols, ix0 = (rem - iy0 * cols) * P;
+    const int tok = 16 * wave + li, ty = tok >> 3, tx = tok & 7;
+    long pix[P];                                      // flat pixel index (n, y, x) of tile p
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int y, x;
+        if (MODE == 0) { y = ty * (H / 8) + iy0; x = tx * (W / 8) + ix0 + p; }
+        else           { y = 8 * iy0 + ty;       x = 8 * (ix0 + p) + tx; }
+        pix[p] = ((long)n * H + y) * W + x;
+    }
+
+    // ---- x0 = relu(conv0(X)) ----
+    f4 x0[NT][P];
+    if constexpr (CIN == 3) {
+        float in[P][3];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const long hw = (long)H * W;
+            const long o = pix[p] - (long)n * hw;     // y*W + x
+#pragma unroll
+            for (int k = 0; k < 3; ++k) in[p][k] = A.X[((long)n * 3 + k) * hw + o];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f4 bias = ldg4(blob + S.conv0_b + 16 * nt + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *wr = blob + S.conv0_w + (16 * nt + 4 * q + r) * 3;
+                const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    x0[nt][p][r] = fmaxf(bias[r] + in[p][0] * w0 + in[p][1] * w1 + in[p][2] * w2, 0.0f);
+            }
+        }
+    } else {
+        init_bias(x0, blob + S.conv0_b, q);
+        gemm<NT, P>(x0, blob + S.conv0_w, 0, CIN / 16, 0, CIN / 16, lane,
+                    [&](int kk, int p) { return ldg4(A.X + pix[p] * CIN + 16 * kk + 4 * q); });
+        relu(x0);
+    }
+
+    // ---- z = GELU(dense1[MODE half](LN(x0))) : u (grid) or v (block) ----
+    {
+        f4 h[NT][P];
+        layernorm(x0, h, blob + S.qln_g, blob + S.qln_b, q);
+        store_slot(slot, h, lane);
+    }
+    auto from_slot = [&](int kk, int p) { return slot[(kk * P + p) * 64 + lane]; };
+    f4 z[NT][P];
+    init_bias(z, blob + S.q1_b + MODE * C, q);
+    gemm<NT, P>(z, blob + S.q1_w, MODE * NT, NT, 0, NT, lane, from_slot);
+    gelu(z);
+
+    // ---- gMLP branch on z ----
+    {
+        f4 h[NT][P];
+        layernorm(z, h, blob + Br.ln_g, blob + Br.ln_b, q);
+        store_slot(slot, h, lane);
+    }
+    f4 ga[NT][P];                                      // gate input a = first C outputs of dense1
+    init_bias(ga, blob + Br.d1_b, q);
+    gemm<NT, P>(ga, blob + Br.d1_w, 0, NT, 0, NT, lane, from_slot);
+    gelu(ga);
+    {
+        f4 gb[NT][P];                                  // b = last C outputs, normalised, then token-mixed
+        init_bias(gb, blob + Br.d1_b + C, q);
+        gemm<NT, P>(gb, blob + Br.d1_w, NT, NT, 0, NT, lane, from_slot);
+        gelu(gb);
+        layernorm(gb, gb, blob + Br.gln_g, blob + Br.gln_b, q);
+        __syncthreads();                               // every wave is done reading its slot
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bT[(p * C + 16 * nt + 4 * q + r) * kBtPitch + tok] = gb[nt][p][r];
+    }
+    __syncthreads();
+    {
+        // mix^T[c][g'] = sum_g bT[c][g] * Wmix[g'][g]; this wave produces its own 16 tokens g'
+        const f4 *wm = reinterpret_cast<const f4 *>(blob + Br.mix_w) + (wave * 4) * 64 + lane;
+        const f4 wm0 = wm[0], wm1 = wm[64], wm2 = wm[128], wm3 = wm[192];
+        const float mb1 = blob[Br.mix_b + tok] + 1.0f;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const float *row = bT + (p * C + 16 * ct + li) * kBtPitch + 4 * q;
+                const f4 a0 = *reinterpret_cast<const f4 *>(row), a1 = *reinterpret_cast<const f4 *>(row + 16),
+                         a2 = *reinterpret_cast<const f4 *>(row + 32), a3 = *reinterpret_cast<const f4 *>(row + 48);
+                f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m = mfma4(a0[j], wm0[j], m);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m = mfma4(a1[j], wm1[j], m);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m = mfma4(a2[j], wm2[j], m);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m = mfma4(a3[j], wm3[j], m);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ga[ct][p][r] *= (m[r] + mb1);
+            }
+    }
+    __syncthreads();                                   // bT is dead; slots are wave-private again
+    store_slot(slot, ga, lane);
+    f4 o[NT][P];
+    init_bias(o, blob + Br.d2_b, q);
+    gemm<NT, P>(o, blob + Br.d2_w, 0, NT, 0, NT, lane, from_slot);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) o[nt][p] += z[nt][p];
+
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                *reinterpret_cast<f4 *>(A.U + pix[p] * C + 16 * nt + 4 * q) = o[nt][p];
+        return;
+    } else {
+        // ---- x1 = dense2(cat[u', v']) + x0 ----
+        store_slot(slot, o, lane);                     // v'
+        f4 x1[NT][P];
+        init_bias(x1, blob + S.q2_b, q);
+        gemm<NT, P>(x1, blob + S.q2_w, 0, 2 * NT, NT, NT, lane, from_slot);
+        gemm<NT, P>(x1, blob + S.q2_w, 0, 2 * NT, 0, NT, lane,
+                    [&](int kk, int p) { return ldg4(A.U + pix[p] * C + 16 * kk + 4 * q); });
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                x1[nt][p] += x0[nt][p];
+                *reinterpret_cast<f4 *>(A.R + pix[p] * C + 16 * nt + 4 * q) = x1[nt][p] + x0[nt][p];
+            }
+        // ---- t = conv2(lrelu(conv1(LN(x1)))) ----
+        layernorm(x1, x1, blob + S.rln_g, blob + S.rln_b, q);
+        store_slot(slot, x1, lane);
+        f4 m1[NT][P];
+        init_bias(m1, blob + S.r1_b, q);
+        gemm<NT, P>(m1, blob + S.r1_w, 0, NT, 0, NT, lane, from_slot);
+        lrelu(m1);
+        store_slot(slot, m1, lane);
+        f4 t[NT][P];
+        init_bias(t, blob + S.r2_b, q);
+        gemm<NT, P>(t, blob + S.r2_w, 0, NT, 0, NT, lane, from_slot);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                *reinterpret_cast<f4 *>(A.T + pix[p] * C + 16 * nt + 4 * q) = t[nt][p];
+                s += t[nt][p];
+            }
+            // channel sums over this wave's 16*P pixels: reduce over the 16 lanes of the quarter
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = s[r];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                if (li == 0) red[wave * C + 16 * nt + 4 * q + r] = v;
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256)
+            A.partial[(long)blockIdx.x * C + c] = (red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// squeeze-excite: s[n, :] = sigmoid(W2 relu(W0 mean_hw(t) + b0) + b2)   (mlp_ma_decoder.py:166-171)
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void se_kernel(const float *blob, StageOff S, const float *partial, int per_img,
+                                                 float inv_hw, float *scale) {
+    constexpr int PARTS = 256 / C > 0 ? 256 / C : 1;
+    __shared__ float s_part[PARTS][C];
+    __shared__ float s_mean[C];
+    __shared__ float s_hid[C / 4];
+    const int n = blockIdx.x;
+    const float *pp = partial + (long)n * per_img * C;
+    for (int c = threadIdx.x % C, part = threadIdx.x / C; part < PARTS; part += PARTS) {   // one pass
+        float acc = 0.0f;
+        for (int i = part; i < per_img; i += PARTS) acc += pp[(long)i * C + c];
+        s_part[part][c] = acc;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.0f;
+        for (int k = 0; k < PARTS; ++k) acc += s_part[k][c];
+        s_mean[c] = acc * inv_hw;
+    }
+    __syncthreads();
+    for (int h = threadIdx.x; h < C / 4; h += 256) {
+        float acc = blob[S.se0_b + h];
+        for (int c = 0; c < C; ++c) acc += blob[S.se0_w + h * C + c] * s_mean[c];
+        s_hid[h] = fmaxf(acc, 0.0f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = blob[S.se2_b + c];
+        for (int h = 0; h < C / 4; ++h) acc += blob[S.se2_w + c * (C / 4) + h] * s_hid[h];
+        scale[(long)n * C + c] = 1.0f / (1.0f + expf(-acc));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// x2 = t * s + r, MaxPool2d(2) -> next stage input, NHWC                 (mlp_ma_decoder.py:232-236)
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ T, const float *__restrict__ R,
+                                                   const float *__restrict__ scale, int B, int H, int W,
+                                                   float *__restrict__ out) {
+    constexpr int G = C / 4;
+    const long total = (long)B * (H / 2) * (W / 2) * G;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        long pxy = i / G;
+        const int xo = (int)(pxy % (W / 2));
+        pxy /= (W / 2);
+        const int yo = (int)(pxy % (H / 2));
+        const int n = (int)(pxy / (H / 2));
+        const f4 s = ldg4(scale + (long)n * C + 4 * g);
+        const long base = (((long)n * H + 2 * yo) * W + 2 * xo) * C + 4 * g;
+        f4 m;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const long o = base + ((long)dy * W + dx) * C;
+                const f4 v = ldg4(T + o) * s + ldg4(R + o);
+                if (dy == 0 && dx == 0) m = v;
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], v[r]);
+            }
+        *reinterpret_cast<f4 *>(out + i * 4) = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage-4 tail + detector head: one wave = 16 pixels of the 1/8-resolution map
+// ------------------------------------------------------------------------------------------------
+struct HeadArgs {
+    const float *blob;
+    StageOff off;            // stage 4 (conv2)
+    int head_w, head_b, head_alpha, head_beta;
+    const float *T, *R, *scale;   // [B,h,w,256], [B,256]
+    int B, h, w;             // 1/8 resolution
+    float *logits;           // [B,65,h,w] or nullptr
+    float *prob;             // [B,8h,8w]
+};
+
+__global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
+    constexpr int C = 256, NT = 16, HT = kHeadNPad / 16;
+    __shared__ __attribute__((aligned(16))) f4 smem[4 * NT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, li = lane & 15;
+    f4 *slot = smem + wave * (NT * 64);
+    const float *blob = A.blob;
+    const long hw = (long)A.h * A.w;
+    const long pixel = ((long)blockIdx.x * 4 + wave) * 16 + li;        // over B*h*w (multiple of 64)
+    const int n = (int)(pixel / hw);
+    const long o = pixel - (long)n * hw;
+    const int i = (int)(o / A.w), j = (int)(o - (long)i * A.w);
+
+    f4 f[NT][1];
+    init_bias(f, blob + A.off.conv2_b, q);
+    gemm<NT, 1>(f, blob + A.off.conv2_w, 0, NT, 0, NT, lane, [&](int kk, int) {
+        const int c = 16 * kk + 4 * q;
+        return ldg4(A.T + pixel * C + c) * ldg4(A.scale + (long)n * C + c) + ldg4(A.R + pixel * C + c);
+    });
+    relu(f);
+    store_slot(slot, f, lane);
+    f4 z[HT][1];
+    init_bias(z, blob + A.head_b, q);
+    gemm<HT, 1>(z, blob + A.head_w, 0, NT, 0, NT, lane, [&](int kk, int) { return slot[kk * 64 + lane]; });
+
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+        const f4 al = ldg4(blob + A.head_alpha + 16 * t + 4 * q), be = ldg4(blob + A.head_beta + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * t + 4 * q + r;
+            z[t][0][r] = z[t][0][r] * al[r] + be[r];
+            if (c < kHeadN) {
+                mx = fmaxf(mx, z[t][0][r]);
+                if (A.logits) A.logits[((long)n * kHeadN + c) * hw + o] = z[t][0][r];
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * t + 4 * q + r;
+            const float e = (c < kHeadN) ? expf(z[t][0][r] - mx) : 0.0f;
+            z[t][0][r] = e;
+            sum += e;
+        }
+    sum = quarter_allreduce(sum);
+    const float inv = 1.0f / sum;
+    const int Wp = 8 * A.w;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {          // channels 0..63: dy = 2t + (q>>1), dx = 4(q&1) + r
+        const f4 pr = z[t][0] * inv;
+        float *dst = A.prob + ((long)n * 8 * A.h + 8 * i + 2 * t + (q >> 1)) * Wp + 8 * j + 4 * (q & 1);
+        *reinterpret_cast<f4 *>(dst) = pr;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct Plan {
+    int mb;                 // images per micro-batch
+    size_t off_U, off_T, off_R, off_X[3], off_partial, off_scale, total;
+};
+
+Plan make_plan(int B, int Hp, int Wp) {
+    Plan p{};
+    const long px = (long)Hp * Wp;
+    long mb = (16L * 1024 * 1024 + px - 1) / px;       // ~16.8 Mpx of stage-1 activations in flight
+    if (mb < 1) mb = 1;
+    if (mb > B) mb = B;
+    p.mb = (int)mb;
+    size_t o = 0;
+    auto take = [&](size_t floats) { size_t r = o; o = balf_align_up(o + floats * sizeof(float), 256); return r; };
+    const size_t big = (size_t)mb * px * 32;           // every stage: H*W*C = px * 32 / 2^(s)
+    p.off_U = take(big);
+    p.off_T = take(big);
+    p.off_R = take(big);
+    p.off_X[0] = take((size_t)mb * (px / 4) * 32);
+    p.off_X[1] = take((size_t)mb * (px / 16) * 64);
+    p.off_X[2] = take((size_t)mb * (px / 64) * 128);
+    p.off_partial = take((size_t)mb * (px / 64) * 32);  // groups/P * C <= px/64 * 32 for every stage
+    p.off_scale = take((size_t)mb * 256);
+    p.total = o;
+    return p;
+}
+
+template <int C, int CIN>
+int run_stage(const float *blob, int s, const float *X, int B, int H, int W, float *U, float *T, float *R,
+              float *partial, float *scale, hipStream_t st) {
+    constexpr int P = StageP<C>::P;
+    constexpr int lds = stage_lds_bytes<C, P>();
+    StageArgs a{blob, kLayout.st[s], X, B, H, W, U, T, R, partial};
+    const int per_img = (H / 8) * (W / 8 / P);
+    const int nwg = B * per_img;
+    auto k0 = stage_branch_kernel<C, CIN, 0>;
+    auto k1 = stage_branch_kernel<C, CIN, 1>;
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess)
+            return BALF_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k0, dim3(nwg), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k1, dim3(nwg), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], partial, per_img,
+                       1.0f / ((float)H * (float)W), scale);
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}
+
+template <int C>
+int run_pool(const float *T, const float *R, const float *scale, int B, int H, int W, float *out, hipStream_t st) {
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(pool_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, st, T, R, scale, B, H, W, out);
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}
+
+}  // namespace
+
+extern "C" size_t balf_forward_workspace_bytes(int B, int Hp, int Wp) {
+    if (B <= 0 || Hp <= 0 || Wp <= 0 || Hp % 64 || Wp % 64) return 0;
+    return make_plan(B, Hp, Wp).total;
+}
+
+extern "C" int balf_forward(const void *packed_dev, int precision, const float *x_nchw_dev, int B, int Hp, int Wp,
+                            float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
+                            void *stream) {
+    if (!packed_dev || !x_nchw_dev || !prob_dev || !workspace_dev) return BALF_ERR_ARG;
+    if (precision != BALF_PREC_FP32) return BALF_ERR_ARG;
+    if (B <= 0 || Hp <= 0 || Wp <= 0) return BALF_ERR_ARG;
+    if (Hp % 64 || Wp % 64) return BALF_ERR_SHAPE;
+    if ((long)B * Hp * Wp * 32 > 0x7fffffffffL) return BALF_ERR_SHAPE;
+    const Plan pl = make_plan(B, Hp, Wp);
+    if (workspace_bytes < pl.total) return BALF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const float *blob = static_cast<const float *>(packed_dev);
+    char *ws = static_cast<char *>(workspace_dev);
+    float *U = reinterpret_cast<float *>(ws + pl.off_U), *T = reinterpret_cast<float *>(ws + pl.off_T),
+          *R = reinterpret_cast<float *>(ws + pl.off_R), *partial = reinterpret_cast<float *>(ws + pl.off_partial),
+          *scale = reinterpret_cast<float *>(ws + pl.off_scale);
+    float *X2 = reinterpret_cast<float *>(ws + pl.off_X[0]), *X3 = reinterpret_cast<float *>(ws + pl.off_X[1]),
+          *X4 = reinterpret_cast<float *>(ws + pl.off_X[2]);
+    const int h8 = Hp / 8, w8 = Wp / 8;
+
+    for (int b0 = 0; b0 < B; b0 += pl.mb) {
+        const int nb = (B - b0 < pl.mb) ? (B - b0) : pl.mb;
+        const float *x = x_nchw_dev + (size_t)b0 * 3 * Hp * Wp;
+        int rc;
+        if ((rc = run_stage<32, 3>(blob, 0, x, nb, Hp, Wp, U, T, R, partial, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_pool<32>(T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<64, 32>(blob, 1, X2, nb, Hp / 2, Wp / 2, U, T, R, partial, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_pool<64>(T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<128, 64>(blob, 2, X3, nb, Hp / 4, Wp / 4, U, T, R, partial, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_pool<128>(T, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<256, 128>(blob, 3, X4, nb, h8, w8, U, T, R, partial, scale, st)) != BALF_OK) return rc;
+        HeadArgs ha{blob, kLayout.st[3], kLayout.head_w, kLayout.head_b, kLayout.head_alpha, kLayout.head_beta,
+                    T, R, scale, nb, h8, w8,
+                    logits_dev ? logits_dev + (size_t)b0 * kHeadN * h8 * w8 : nullptr,
+                    prob_dev + (size_t)b0 * Hp * Wp};
+        hipLaunchKernelGGL(head_kernel, dim3((unsigned)((long)nb * h8 * w8 / 64)), dim3(256), 0, st, ha);
+        BALF_LAUNCH_CHECK();
+    }
+    return BALF_OK;
+}

@@ -1,0 +1,94 @@
+// Packed-weight blob layout shared by the host packer (weights.hip) and the kernels (detector.hip).
+//
+// All offsets are in floats from the start of the blob and are multiples of 64 floats (256 B).
+// Linear weights that feed the MFMA are stored in "A-fragment order" for v_mfma_f32_16x16x4_f32:
+//   frag(nt, kt)[lane][j] = W[16*nt + (lane & 15)][16*kt + 4*(lane >> 4) + j]      j = 0..3
+// laid out as float4[(nt * K/16 + kt) * 64 + lane], so one wave-wide 16-byte load fetches a whole
+// 16(out) x 16(in) weight tile as 1 KiB of contiguous memory, and element j feeds MFMA k-step j
+// (the k-slot `lane >> 4` of step j carries input channel 16*kt + 4*(lane>>4) + j, which is exactly
+// the register the accumulator layout of the previous MFMA left that channel in).
+#pragma once
+
+namespace balf {
+
+constexpr int kStages = 4;
+constexpr int kC[kStages] = {32, 64, 128, 256};
+constexpr int kCin[kStages] = {3, 32, 64, 128};
+constexpr int kTokens = 64;       // 8x8 grid cells / 8x8 block positions
+constexpr int kHeadN = 65;        // 64 cell positions + dustbin
+constexpr int kHeadNPad = 80;     // padded to a multiple of 16 output rows
+constexpr float kLnEps = 1e-5f;
+constexpr float kBnEps = 1e-5f;
+
+struct BranchOff {                // GridGmlpLayer / BlockGmlpLayer
+    int ln_g, ln_b;               // .norm
+    int d1_w, d1_b;               // .dense1  [2C, C]   frags
+    int gln_g, gln_b;             // .{grid,block}_gating_unit.norm
+    int mix_w, mix_b;             // .{grid,block}_gating_unit.dense [64, 64] frags
+    int d2_w, d2_b;               // .dense2  [C, C]    frags
+};
+
+struct StageOff {
+    int conv0_w, conv0_b;         // .conv.0 [C, Cin]: plain row-major for stage 1 (Cin = 3), frags otherwise
+    int qln_g, qln_b;             // RSHMAG .norm
+    int q1_w, q1_b;               // RSHMAG .dense1 [2C, C] frags
+    BranchOff br[2];              // 0 = grid, 1 = block
+    int q2_w, q2_b;               // RSHMAG .dense2 [C, 2C] frags
+    int rln_g, rln_b;             // RCAB .norm
+    int r1_w, r1_b, r2_w, r2_b;   // RCAB .conv1 / .conv2 [C, C] frags
+    int se0_w, se0_b;             // calayer.excite.0 [C/4, C] plain
+    int se2_w, se2_b;             // calayer.excite.2 [C, C/4] plain
+    int conv2_w, conv2_b;         // .conv2 [C, C] frags (stage 4 only; dead weight elsewhere)
+};
+
+struct Layout {
+    StageOff st[kStages];
+    int head_w;                   // detector_head.dense [80(pad), 256] frags
+    int head_b;                   // [80] dense bias
+    int head_alpha, head_beta;    // [80] BatchNorm(eval) as z = lin * alpha + beta
+    int total;                    // floats
+};
+
+constexpr int align64(int v) { return (v + 63) / 64 * 64; }
+
+constexpr Layout make_layout() {
+    Layout L{};
+    int o = 0;
+    auto take = [&](int n) { int r = o; o = align64(o + n); return r; };
+    for (int s = 0; s < kStages; ++s) {
+        const int C = kC[s], Cin = kCin[s];
+        StageOff &S = L.st[s];
+        S.conv0_w = take(C * Cin); S.conv0_b = take(C);
+        S.qln_g = take(C); S.qln_b = take(C);
+        S.q1_w = take(2 * C * C); S.q1_b = take(2 * C);
+        for (int b = 0; b < 2; ++b) {
+            BranchOff &B = S.br[b];
+            B.ln_g = take(C); B.ln_b = take(C);
+            B.d1_w = take(2 * C * C); B.d1_b = take(2 * C);
+            B.gln_g = take(C); B.gln_b = take(C);
+            B.mix_w = take(kTokens * kTokens); B.mix_b = take(kTokens);
+            B.d2_w = take(C * C); B.d2_b = take(C);
+        }
+        S.q2_w = take(2 * C * C); S.q2_b = take(C);
+        S.rln_g = take(C); S.rln_b = take(C);
+        S.r1_w = take(C * C); S.r1_b = take(C);
+        S.r2_w = take(C * C); S.r2_b = take(C);
+        S.se0_w = take(C / 4 * C); S.se0_b = take(C / 4);
+        S.se2_w = take(C * (C / 4)); S.se2_b = take(C);
+        S.conv2_w = take(C * C); S.conv2_b = take(C);
+    }
+    L.head_w = take(kHeadNPad * kC[3]);
+    L.head_b = take(kHeadNPad);
+    L.head_alpha = take(kHeadNPad);
+    L.head_beta = take(kHeadNPad);
+    L.total = o;
+    return L;
+}
+
+constexpr Layout kLayout = make_layout();
+
+// Number of floating-point state tensors: 40 per stage + 6 head entries.
+constexpr int kTensorsPerStage = 40;
+constexpr int kNumStateTensors = kStages * kTensorsPerStage + 6;
+
+}  // namespace balf

@@ -1,0 +1,420 @@
+// Window-max NMS + exact K-th-threshold top-K on the score map, gfx950.
+//
+// Replaces (bit-exact on identical input) the reference's NumPy/SciPy post-processing:
+//   crop                        /root/reference/balf/utils/train_utils.py:437-442
+//   remove_borders              /root/reference/balf/utils/test_utils.py:34-47
+//   apply_nms (maximum_filter)  /root/reference/balf/utils/test_utils.py:50-54
+//   find_index_higher_scores    /root/reference/balf/utils/test_utils.py:74-95
+//   final sort                  /root/reference/balf/utils/train_utils.py:451-452
+//
+// Kernels (all HBM-bound scans, no MFMA):
+//   nms_tile_kernel<SIZE>  one 64x64 output tile per workgroup: tile + halo -> LDS with the crop
+//                          offset and the border zeroing applied on the fly; separable window max
+//                          (row pass, column pass; doubling trick for SIZE 15); survivors
+//                          (v > 0 && v == window max) appended to a per-image list with one global
+//                          atomic per workgroup, or, in dense mode, the apply_nms map is written.
+//   topk_select_kernel     one workgroup per image: MSB-first radix select of the K-th largest
+//                          survivor score (positive floats order like uint32); if more than K
+//                          survivors reach it, a second radix select on the flat index keeps the
+//                          raster-first K of them (as the reference does); LDS bitonic sort of the
+//                          <= K selected (score desc, index asc) and the padded output rows.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 64;   // tile height (outputs)
+constexpr int TW = 64;   // tile width  (outputs)
+constexpr int SEG = 16;  // outputs per thread along the sliding axis
+constexpr int NTHREADS = 256;
+
+template <int SIZE, int N>
+__device__ __forceinline__ void window_max_1d(const float (&v)[N + SIZE - 1], float (&o)[N]) {
+    if constexpr (SIZE == 15) {
+        // max is idempotent, so overlapping windows combine: 2 -> 4 -> 8 -> 15 (= 8 + 8, overlap 1)
+        constexpr int L = N + 14;
+        float a[L - 1], b[L - 3], c[L - 7];
+#pragma unroll
+        for (int i = 0; i < L - 1; ++i) a[i] = fmaxf(v[i], v[i + 1]);
+#pragma unroll
+        for (int i = 0; i < L - 3; ++i) b[i] = fmaxf(a[i], a[i + 2]);
+#pragma unroll
+        for (int i = 0; i < L - 7; ++i) c[i] = fmaxf(b[i], b[i + 4]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) o[i] = fmaxf(c[i], c[i + 7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            float m = v[i];
+#pragma unroll
+            for (int k = 1; k < SIZE; ++k) m = fmaxf(m, v[i + k]);
+            o[i] = m;
+        }
+    }
+}
+
+struct NmsArgs {
+    const float *src;      // [B, Hs, Ws]
+    int Hs, Ws;            // pitch of the source maps
+    int crop_y, crop_x;    // score(y,x) = src[b, crop_y + y, crop_x + x]
+    int H, W;              // cropped size
+    int border;
+    int size;              // nms window side (runtime copy)
+    int2 *surv;            // [B, cap] (flat idx, score bits)   (sparse mode)
+    int *surv_count;       // [B]
+    long cap;
+    float *dense;          // [B, H, W] apply_nms output         (dense mode) or nullptr
+};
+
+__device__ __forceinline__ float load_score(const NmsArgs &a, const float *img, int y, int x) {
+    if (y < 0 || y >= a.H || x < 0 || x >= a.W) return -INFINITY;          // clipped window
+    if (y < a.border || y >= a.H - a.border || x < a.border || x >= a.W - a.border) return 0.0f;
+    return img[(long)(a.crop_y + y) * a.Ws + (a.crop_x + x)];
+}
+
+// Block-wide exclusive scan of one int per thread (256 threads = 4 waves); returns the exclusive
+// prefix and leaves the block total in *total.
+__device__ __forceinline__ int block_exclusive_scan(int v, int *s_wave /*[4]*/, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) base += (w < wave) ? s_wave[w] : 0;
+    *total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    return base + inc - v;
+}
+
+template <int SIZE>
+__global__ __launch_bounds__(NTHREADS) void nms_tile_kernel(NmsArgs a) {
+    constexpr int R = SIZE - 1;
+    constexpr int LO = SIZE / 2;              // window = [i - LO, i + (SIZE-1)/2]
+    constexpr int IN_H = TH + R, IN_W = TW + R;
+    constexpr int PIN = IN_W | 1;             // odd pitch: lanes walk rows in the row pass
+    constexpr int PROW = TW + 1;
+    __shared__ float s_in[IN_H * PIN];
+    __shared__ float s_row[IN_H * PROW];
+    __shared__ int s_scan[4];
+    __shared__ int s_base;
+
+    const int b = blockIdx.z;
+    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
+    const float *img = a.src + (long)b * a.Hs * a.Ws;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < IN_H * IN_W; i += NTHREADS) {
+        const int r = i / IN_W, c = i - r * IN_W;
+        s_in[r * PIN + c] = load_score(a, img, ty0 - LO + r, tx0 - LO + c);
+    }
+    __syncthreads();
+
+    // row pass: item = (row, 16-column segment); consecutive lanes take consecutive rows
+    for (int item = tid; item < IN_H * (TW / SEG); item += NTHREADS) {
+        const int r = item % IN_H, seg = item / IN_H;
+        float v[SEG + R], o[SEG];
+#pragma unroll
+        for (int k = 0; k < SEG + R; ++k) v[k] = s_in[r * PIN + seg * SEG + k];
+        window_max_1d<SIZE, SEG>(v, o);
+#pragma unroll
+        for (int k = 0; k < SEG; ++k) s_row[r * PROW + seg * SEG + k] = o[k];
+    }
+    __syncthreads();
+
+    // column pass: thread = (column, 16-row segment)
+    const int x = tid & (TW - 1), seg = tid / TW;
+    float v[SEG + R], m[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG + R; ++k) v[k] = s_row[(seg * SEG + k) * PROW + x];
+    window_max_1d<SIZE, SEG>(v, m);
+
+    const int gx = tx0 + x;
+    unsigned keepmask = 0;
+    float cen[SEG];
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+        const int gy = ty0 + seg * SEG + j;
+        cen[j] = s_in[(seg * SEG + j + LO) * PIN + x + LO];
+        const bool inside = (gy < a.H) && (gx < a.W);
+        const bool keep = inside && (cen[j] == m[j]);
+        if (a.dense != nullptr) {
+            if (inside) a.dense[((long)b * a.H + gy) * a.W + gx] = cen[j] * (keep ? 1.0f : 0.0f);
+        } else if (keep && cen[j] > 0.0f) {
+            keepmask |= 1u << j;
+        }
+    }
+    if (a.dense != nullptr) return;
+
+    int total;
+    const int excl = block_exclusive_scan(__popc(keepmask), s_scan, &total);
+    if (total == 0) return;                                   // block-uniform
+    if (tid == 0) s_base = atomicAdd(&a.surv_count[b], total);
+    __syncthreads();
+    long pos = (long)b * a.cap + s_base + excl;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+        if (keepmask & (1u << j)) {
+            const int gy = ty0 + seg * SEG + j;
+            a.surv[pos++] = make_int2(gy * a.W + gx, __float_as_int(cen[j]));
+        }
+    }
+}
+
+// Any window size up to BALF_MAX_NMS_SIZE: plain per-output loops over the LDS tile.
+__global__ __launch_bounds__(NTHREADS) void nms_tile_kernel_generic(NmsArgs a) {
+    constexpr int RMAX = BALF_MAX_NMS_SIZE - 1;
+    constexpr int PIN = (TW + RMAX) | 1;
+    constexpr int PROW = TW + 1;
+    __shared__ float s_in[(TH + RMAX) * PIN];
+    __shared__ float s_row[(TH + RMAX) * PROW];
+    __shared__ int s_scan[4];
+    __shared__ int s_base;
+
+    const int size = a.size, R = size - 1, LO = size / 2;
+    const int IN_H = TH + R, IN_W = TW + R;
+    const int b = blockIdx.z;
+    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
+    const float *img = a.src + (long)b * a.Hs * a.Ws;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < IN_H * IN_W; i += NTHREADS) {
+        const int r = i / IN_W, c = i - r * IN_W;
+        s_in[r * PIN + c] = load_score(a, img, ty0 - LO + r, tx0 - LO + c);
+    }
+    __syncthreads();
+    for (int i = tid; i < IN_H * TW; i += NTHREADS) {
+        const int r = i / TW, c = i - r * TW;
+        float m = s_in[r * PIN + c];
+        for (int k = 1; k < size; ++k) m = fmaxf(m, s_in[r * PIN + c + k]);
+        s_row[r * PROW + c] = m;
+    }
+    __syncthreads();
+
+    const int x = tid & (TW - 1), seg = tid / TW;
+    const int gx = tx0 + x;
+    unsigned keepmask = 0;
+    float cen[SEG];
+    for (int j = 0; j < SEG; ++j) {
+        const int ry = seg * SEG + j;
+        float m = s_row[ry * PROW + x];
+        for (int k = 1; k < size; ++k) m = fmaxf(m, s_row[(ry + k) * PROW + x]);
+        const int gy = ty0 + ry;
+        cen[j] = s_in[(ry + LO) * PIN + x + LO];
+        const bool inside = (gy < a.H) && (gx < a.W);
+        const bool keep = inside && (cen[j] == m);
+        if (a.dense != nullptr) {
+            if (inside) a.dense[((long)b * a.H + gy) * a.W + gx] = cen[j] * (keep ? 1.0f : 0.0f);
+        } else if (keep && cen[j] > 0.0f) {
+            keepmask |= 1u << j;
+        }
+    }
+    if (a.dense != nullptr) return;
+
+    int total;
+    const int excl = block_exclusive_scan(__popc(keepmask), s_scan, &total);
+    if (total == 0) return;
+    if (tid == 0) s_base = atomicAdd(&a.surv_count[b], total);
+    __syncthreads();
+    long pos = (long)b * a.cap + s_base + excl;
+    for (int j = 0; j < SEG; ++j) {
+        if (keepmask & (1u << j)) {
+            const int gy = ty0 + seg * SEG + j;
+            a.surv[pos++] = make_int2(gy * a.W + gx, __float_as_int(cen[j]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// top-K selection: one 1024-thread workgroup per image
+// ---------------------------------------------------------------------------------------------
+constexpr int SEL_THREADS = 1024;
+
+// Radix select over 32-bit keys of the elements that pass `pred`.  Finds the key of rank `rank`
+// (1-based) counting from the top (FROM_TOP) or from the bottom; *n_same = how many elements carry
+// exactly that key and *rank_in_same = how many of them are needed to reach `rank`.
+template <bool FROM_TOP, typename KeyFn>
+__device__ unsigned radix_select(int n, int rank, KeyFn key_of, unsigned *s_hist /*[256]*/, int *s_tmp /*[4]*/,
+                                 int *n_same, int *rank_in_same) {
+    unsigned prefix = 0, mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += SEL_THREADS) s_hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += SEL_THREADS) {
+            unsigned k;
+            if (key_of(i, &k) && (k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int cum = 0, chosen = 0, r = rank;
+            for (int t = 0; t < 256; ++t) {
+                const int bin = FROM_TOP ? 255 - t : t;
+                const int h = (int)s_hist[bin];
+                if (cum + h >= r) { chosen = bin; r -= cum; s_tmp[2] = h; break; }
+                cum += h;
+            }
+            s_tmp[0] = chosen;
+            s_tmp[1] = r;
+        }
+        __syncthreads();
+        prefix |= (unsigned)s_tmp[0] << shift;
+        mask |= 255u << shift;
+        rank = s_tmp[1];
+        __syncthreads();
+    }
+    *n_same = s_tmp[2];
+    *rank_in_same = rank;
+    return prefix;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const int2 *surv_all, const int *surv_count,
+                                                                  long cap, int K, int npow2, int32_t *idx_out,
+                                                                  float *score_out, int32_t *count_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);       // [npow2]
+    unsigned *s_hist = reinterpret_cast<unsigned *>(keys + npow2);                 // [256]
+    int *s_tmp = reinterpret_cast<int *>(s_hist + 256);                            // [4]
+    int *s_cnt = s_tmp + 4;                                                        // [1]
+
+    const int b = blockIdx.x;
+    const int2 *surv = surv_all + (long)b * cap;
+    const int n = surv_count[b];
+    int32_t *idx_o = idx_out + (long)b * K;
+    float *sc_o = score_out + (long)b * K;
+
+    if (n == 0) {
+        // No positive NMS score: the reference's threshold falls back to 0.0 and `map >= 0` holds
+        // everywhere, so it returns the first K pixels in raster order (test_utils.py:84-95).
+        for (int i = threadIdx.x; i < K; i += SEL_THREADS) { idx_o[i] = i; sc_o[i] = 0.0f; }
+        if (threadIdx.x == 0) count_out[b] = K;
+        return;
+    }
+
+    // Selected set = the first K pixels in raster order among those with score >= thr, where thr is the
+    // K-th largest score: with ties at thr this can drop a later, higher-scoring pixel -- that is what
+    // `argwhere(map >= thr)[:K]` does (test_utils.py:93-95).
+    unsigned thr = 0;            // score bits; select score >= thr with idx <= idx_cut
+    int idx_cut = 0x7fffffff;
+    if (n > K) {
+        int n_eq, need_eq;
+        thr = radix_select<true>(n, K, [&](int i, unsigned *k) { *k = (unsigned)surv[i].y; return true; },
+                                 s_hist, s_tmp, &n_eq, &need_eq);
+        if (n_eq > need_eq) {    // more than K candidates reach the threshold: keep the raster-first K
+            int d0, d1;
+            idx_cut = (int)radix_select<false>(
+                n, K,
+                [&](int i, unsigned *k) { int2 e = surv[i]; *k = (unsigned)e.x; return (unsigned)e.y >= thr; },
+                s_hist, s_tmp, &d0, &d1);
+        }
+    }
+
+    if (threadIdx.x == 0) *s_cnt = 0;
+    for (int i = threadIdx.x; i < npow2; i += SEL_THREADS) keys[i] = ~0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += SEL_THREADS) {
+        const int2 e = surv[i];
+        const unsigned sb = (unsigned)e.y;
+        if (sb >= thr && e.x <= idx_cut) {
+            const int p = atomicAdd(s_cnt, 1);
+            keys[p] = ((unsigned long long)(~sb) << 32) | (unsigned)e.x;   // ascending = score desc, idx asc
+        }
+    }
+    __syncthreads();
+    const int cnt = *s_cnt;
+
+    for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npow2; i += SEL_THREADS) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = keys[i], y = keys[l];
+                    const bool up = ((i & k) == 0);
+                    if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < K; i += SEL_THREADS) {
+        if (i < cnt) {
+            const unsigned long long kv = keys[i];
+            idx_o[i] = (int32_t)(unsigned)(kv & 0xffffffffull);
+            sc_o[i] = __uint_as_float(~(unsigned)(kv >> 32));
+        } else {
+            idx_o[i] = -1;
+            sc_o[i] = 0.0f;
+        }
+    }
+    if (threadIdx.x == 0) count_out[b] = cnt;
+}
+
+int launch_nms_tiles(const NmsArgs &a, int B, hipStream_t stream) {
+    dim3 grid(balf_ceil_div(a.W, TW), balf_ceil_div(a.H, TH), B), block(NTHREADS);
+    switch (a.size) {
+        case 15: hipLaunchKernelGGL(nms_tile_kernel<15>, grid, block, 0, stream, a); break;
+        case 5: hipLaunchKernelGGL(nms_tile_kernel<5>, grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(nms_tile_kernel<3>, grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL(nms_tile_kernel_generic, grid, block, 0, stream, a); break;
+    }
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}
+
+int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int balf_window_nms(const float *score_dev, int B, int H, int W, int border, int nms_size,
+                               float *out_dev, void *stream) {
+    if (!score_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || border < 0) return BALF_ERR_ARG;
+    if (nms_size < 1 || nms_size > BALF_MAX_NMS_SIZE) return BALF_ERR_ARG;
+    if ((long)H * W > 0x7fffffffL) return BALF_ERR_SHAPE;
+    NmsArgs a{score_dev, H, W, 0, 0, H, W, border, nms_size, nullptr, nullptr, 0, out_dev};
+    return launch_nms_tiles(a, B, (hipStream_t)stream);
+}
+
+extern "C" size_t balf_nms_topk_workspace_bytes(int B, int H, int W, int K) {
+    if (B <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
+    // [B] survivor counters (padded to 256 B) + [B, H*W] (idx, score) survivor slots.  Only slots that
+    // receive a survivor are ever touched; H*W is the exact worst case (a constant plateau).
+    return balf_align_up((size_t)B * sizeof(int), 256) + (size_t)B * (size_t)H * (size_t)W * sizeof(int2);
+}
+
+extern "C" int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W,
+                             int border, int nms_size, int K, int32_t *idx_dev, float *score_dev,
+                             int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    if (!prob_dev || !idx_dev || !score_dev || !count_dev || !workspace_dev) return BALF_ERR_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || K <= 0 || border < 0) return BALF_ERR_ARG;
+    if (nms_size < 1 || nms_size > BALF_MAX_NMS_SIZE || K > BALF_MAX_TOPK) return BALF_ERR_ARG;
+    if (crop_y < 0 || crop_x < 0 || crop_y + H > Hp || crop_x + W > Wp) return BALF_ERR_SHAPE;
+    if ((long)H * W > 0x7fffffffL || (long)K > (long)H * W) return BALF_ERR_SHAPE;
+    if (workspace_bytes < balf_nms_topk_workspace_bytes(B, H, W, K)) return BALF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+
+    int *counts = reinterpret_cast<int *>(workspace_dev);
+    int2 *surv = reinterpret_cast<int2 *>(reinterpret_cast<char *>(workspace_dev) +
+                                          balf_align_up((size_t)B * sizeof(int), 256));
+    if (hipMemsetAsync(counts, 0, balf_align_up((size_t)B * sizeof(int), 256), st) != hipSuccess)
+        return BALF_ERR_LAUNCH;
+    NmsArgs a{prob_dev, Hp, Wp, crop_y, crop_x, H, W, border, nms_size, surv, counts, (long)H * W, nullptr};
+    int rc = launch_nms_tiles(a, B, st);
+    if (rc != BALF_OK) return rc;
+
+    const int npow2 = next_pow2(K);
+    const size_t smem = (size_t)npow2 * 8 + 256 * 4 + 8 * 4;
+    if (smem > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_select_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return BALF_ERR_LAUNCH;
+    hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(SEL_THREADS), smem, st, surv, counts, (long)H * W, K,
+                       npow2, idx_dev, score_dev, count_dev);
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}

@@ -1,0 +1,167 @@
+// Host side of the weight path: the state-dict table the library expects and the packer that turns
+// the reference's nn.Linear / LayerNorm / BatchNorm tensors into the MFMA-fragment-ordered blob of
+// layout.h.  Replaces MLP_MA_DECODER.load_state_dict as reached from
+// /root/reference/balf/model/get_model.py:60-67 (tensor names and shapes are that state_dict's).
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "layout.h"
+
+namespace {
+
+using namespace balf;
+
+struct Entry {
+    std::string name;
+    size_t numel;
+};
+
+const std::vector<Entry> &table() {
+    static const std::vector<Entry> t = [] {
+        std::vector<Entry> v;
+        const std::string rsh = "residual_split_head_multi_axis_gmlp_layer";
+        const std::string rcab = "residual_channel_attention_block";
+        for (int s = 0; s < kStages; ++s) {
+            const size_t C = kC[s], Cin = kCin[s];
+            const std::string d = "down" + std::to_string(s + 1) + ".";
+            auto lin = [&](const std::string &n, size_t o, size_t i) {
+                v.push_back({d + n + ".weight", o * i});
+                v.push_back({d + n + ".bias", o});
+            };
+            auto ln = [&](const std::string &n) {
+                v.push_back({d + n + ".weight", C});
+                v.push_back({d + n + ".bias", C});
+            };
+            lin("conv.0", C, Cin);
+            ln(rsh + ".norm");
+            lin(rsh + ".dense1", 2 * C, C);
+            const char *br[2] = {"grid_gmlp_layer", "block_gmlp_layer"};
+            const char *un[2] = {"grid_gating_unit", "block_gating_unit"};
+            for (int b = 0; b < 2; ++b) {
+                const std::string p = rsh + "." + br[b];
+                ln(p + ".norm");
+                lin(p + ".dense1", 2 * C, C);
+                ln(p + "." + un[b] + ".norm");
+                lin(p + "." + un[b] + ".dense", kTokens, kTokens);
+                lin(p + ".dense2", C, C);
+            }
+            lin(rsh + ".dense2", C, 2 * C);
+            ln(rcab + ".norm");
+            lin(rcab + ".conv1", C, C);
+            lin(rcab + ".conv2", C, C);
+            lin(rcab + ".calayer.excite.0", C / 4, C);
+            lin(rcab + ".calayer.excite.2", C, C / 4);
+            lin("conv2", C, C);
+        }
+        v.push_back({"detector_head.dense.weight", (size_t)kHeadN * kC[3]});
+        v.push_back({"detector_head.dense.bias", (size_t)kHeadN});
+        v.push_back({"detector_head.norm.weight", (size_t)kHeadN});
+        v.push_back({"detector_head.norm.bias", (size_t)kHeadN});
+        v.push_back({"detector_head.norm.running_mean", (size_t)kHeadN});
+        v.push_back({"detector_head.norm.running_var", (size_t)kHeadN});
+        return v;
+    }();
+    return t;
+}
+
+// W [N, K] row-major -> A-fragment order, output rows padded with zeros up to Npad.
+void pack_frags(float *dst, const float *W, int N, int K, int Npad) {
+    const int KT = K / 16;
+    for (int nt = 0; nt < Npad / 16; ++nt)
+        for (int kt = 0; kt < KT; ++kt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = 16 * nt + (lane & 15);
+                    const int k = 16 * kt + 4 * (lane >> 4) + j;
+                    dst[(((size_t)nt * KT + kt) * 64 + lane) * 4 + j] = n < N ? W[(size_t)n * K + k] : 0.0f;
+                }
+}
+
+void copy(float *dst, const float *src, size_t n) { memcpy(dst, src, n * sizeof(float)); }
+
+}  // namespace
+
+extern "C" int balf_num_state_tensors(void) { return (int)table().size(); }
+
+extern "C" const char *balf_state_tensor_name(int i) {
+    if (i < 0 || i >= (int)table().size()) return nullptr;
+    return table()[i].name.c_str();
+}
+
+extern "C" size_t balf_state_tensor_numel(int i) {
+    if (i < 0 || i >= (int)table().size()) return 0;
+    return table()[i].numel;
+}
+
+extern "C" size_t balf_packed_weights_bytes(int precision) {
+    if (precision != BALF_PREC_FP32) return 0;
+    return (size_t)kLayout.total * sizeof(float);
+}
+
+extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int precision, void *packed_host,
+                                 size_t packed_bytes) {
+    if (!tensors || !packed_host) return BALF_ERR_ARG;
+    if (n_tensors != kNumStateTensors || (int)table().size() != kNumStateTensors) return BALF_ERR_ARG;
+    if (precision != BALF_PREC_FP32) return BALF_ERR_ARG;
+    if (packed_bytes < balf_packed_weights_bytes(precision)) return BALF_ERR_WORKSPACE;
+    for (int i = 0; i < n_tensors; ++i)
+        if (!tensors[i]) return BALF_ERR_ARG;
+
+    float *blob = static_cast<float *>(packed_host);
+    memset(blob, 0, (size_t)kLayout.total * sizeof(float));
+    for (int s = 0; s < kStages; ++s) {
+        const int C = kC[s], Cin = kCin[s];
+        const StageOff &S = kLayout.st[s];
+        const float *const *t = tensors + s * kTensorsPerStage;
+        if (s == 0) copy(blob + S.conv0_w, t[0], (size_t)C * Cin);
+        else pack_frags(blob + S.conv0_w, t[0], C, Cin, C);
+        copy(blob + S.conv0_b, t[1], C);
+        copy(blob + S.qln_g, t[2], C);
+        copy(blob + S.qln_b, t[3], C);
+        pack_frags(blob + S.q1_w, t[4], 2 * C, C, 2 * C);
+        copy(blob + S.q1_b, t[5], 2 * C);
+        for (int b = 0; b < 2; ++b) {
+            const BranchOff &B = S.br[b];
+            const float *const *u = t + 6 + 10 * b;
+            copy(blob + B.ln_g, u[0], C);
+            copy(blob + B.ln_b, u[1], C);
+            pack_frags(blob + B.d1_w, u[2], 2 * C, C, 2 * C);
+            copy(blob + B.d1_b, u[3], 2 * C);
+            copy(blob + B.gln_g, u[4], C);
+            copy(blob + B.gln_b, u[5], C);
+            pack_frags(blob + B.mix_w, u[6], kTokens, kTokens, kTokens);
+            copy(blob + B.mix_b, u[7], kTokens);
+            pack_frags(blob + B.d2_w, u[8], C, C, C);
+            copy(blob + B.d2_b, u[9], C);
+        }
+        pack_frags(blob + S.q2_w, t[26], C, 2 * C, C);
+        copy(blob + S.q2_b, t[27], C);
+        copy(blob + S.rln_g, t[28], C);
+        copy(blob + S.rln_b, t[29], C);
+        pack_frags(blob + S.r1_w, t[30], C, C, C);
+        copy(blob + S.r1_b, t[31], C);
+        pack_frags(blob + S.r2_w, t[32], C, C, C);
+        copy(blob + S.r2_b, t[33], C);
+        copy(blob + S.se0_w, t[34], (size_t)(C / 4) * C);
+        copy(blob + S.se0_b, t[35], C / 4);
+        copy(blob + S.se2_w, t[36], (size_t)C * (C / 4));
+        copy(blob + S.se2_b, t[37], C);
+        pack_frags(blob + S.conv2_w, t[38], C, C, C);
+        copy(blob + S.conv2_b, t[39], C);
+    }
+    const float *const *h = tensors + kStages * kTensorsPerStage;
+    pack_frags(blob + kLayout.head_w, h[0], kHeadN, kC[3], kHeadNPad);
+    copy(blob + kLayout.head_b, h[1], kHeadN);
+    for (int c = 0; c < kHeadN; ++c) {
+        // BatchNorm2d in eval mode (/root/reference/balf/model/decoder.py:12,22):
+        // (x - mean) / sqrt(var + eps) * weight + bias  ==  x * alpha + beta
+        const double alpha = (double)h[2][c] / sqrt((double)h[5][c] + (double)kBnEps);
+        blob[kLayout.head_alpha + c] = (float)alpha;
+        blob[kLayout.head_beta + c] = (float)((double)h[3][c] - (double)h[4][c] * alpha);
+    }
+    return BALF_OK;
+}

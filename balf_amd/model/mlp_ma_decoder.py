@@ -1,0 +1,143 @@
+"""``MLP_MA_DECODER``: the reference's detector as a parameter container whose forward runs on the
+HIP library.
+
+Mirrors /root/reference/balf/model/mlp_ma_decoder.py:246-285 at the interface level only: the module
+tree is built so that ``state_dict()`` has exactly the reference's 167 names/shapes/dtypes (the
+contract ``get_model.load_test_pretrained_model`` filters on, get_model.py:60-67, :84), and
+``forward(x)`` returns ``{'logits', 'prob'}`` like decoder.py:30.  No layer here has a Python
+``forward`` of its own: the whole network is one call into ``balf_forward`` (include/balf_hip.h).
+There is no CPU path; a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, arch, ops
+from .._lib import BalfHipError, check, lib
+
+
+class _Holder(nn.Module):
+    """Plain container; exists so that parameter names nest like the reference's modules."""
+
+
+def _linear(i, o):
+    return nn.Linear(i, o)
+
+
+def _gmlp(c, factor, tokens, unit_name):
+    m = _Holder()
+    m.norm = nn.LayerNorm(c)
+    m.dense1 = _linear(c, c * factor)
+    unit = _Holder()
+    unit.norm = nn.LayerNorm(c)
+    unit.dense = _linear(tokens, tokens)
+    setattr(m, unit_name, unit)
+    m.dense2 = _linear(c, c)
+    return m
+
+
+def _down(cin, c, a):
+    d = _Holder()
+    d.conv = nn.Sequential(_linear(cin, c), nn.ReLU(inplace=True))
+    r = _Holder()
+    r.norm = nn.LayerNorm(c)
+    r.dense1 = _linear(c, c * a["input_proj_factor"])
+    r.grid_gmlp_layer = _gmlp(c, a["grid_gmlp_factor"], a["grid_size"][0] * a["grid_size"][1], "grid_gating_unit")
+    r.block_gmlp_layer = _gmlp(c, a["block_gmlp_factor"], a["block_size"][0] * a["block_size"][1],
+                               "block_gating_unit")
+    r.dense2 = _linear(c * a["input_proj_factor"], c)
+    d.residual_split_head_multi_axis_gmlp_layer = r
+    k = _Holder()
+    k.norm = nn.LayerNorm(c)
+    k.conv1 = _linear(c, c)
+    k.conv2 = _linear(c, c)
+    ca = _Holder()
+    red = a["channels_reduction"]
+    ca.excite = nn.Sequential(_linear(c, c // red), nn.ReLU(inplace=True), _linear(c // red, c), nn.Sigmoid())
+    k.calayer = ca
+    d.residual_channel_attention_block = k
+    d.conv2 = _linear(c, c)
+    return d
+
+
+class MLP_MA_DECODER(nn.Module):
+    def __init__(self, model_cfg, precision: str = "fp32"):
+        super().__init__()
+        a = {k: model_cfg[k] for k in ("en_embed_dims", "grid_size", "block_size", "grid_gmlp_factor",
+                                       "block_gmlp_factor", "input_proj_factor", "channels_reduction",
+                                       "cell_size")}          # KeyError on a missing key, like the reference
+        arch.check_supported(a)
+        dims = a["en_embed_dims"]
+        for s in range(4):
+            setattr(self, f"down{s + 1}", _down(dims[s], dims[s + 1], a))
+        head = _Holder()
+        head.dense = _linear(dims[4], a["cell_size"] ** 2 + 1)
+        head.norm = nn.BatchNorm2d(a["cell_size"] ** 2 + 1)
+        self.detector_head = head
+        self.precision = precision
+        self._packed = None            # (device blob, key) cache; rebuilt when parameters change
+        self._packed_key = None
+
+    # ---- weights -> packed device blob -------------------------------------------------------
+    def _precision_code(self) -> int:
+        try:
+            return {"fp32": _lib.PREC_FP32, "fp16": _lib.PREC_FP16}[self.precision]
+        except KeyError:
+            raise ValueError(f"precision must be 'fp32' or 'fp16', got {self.precision!r}")
+
+    def _state_key(self, device):
+        return (str(device), self.precision,
+                tuple((t.data_ptr(), t._version) for t in self.state_dict().values()))
+
+    def packed_weights(self, device) -> torch.Tensor:
+        key = self._state_key(device)
+        if self._packed is None or self._packed_key != key:
+            l = lib()
+            sd = self.state_dict()
+            n = l.balf_num_state_tensors()
+            host = []
+            for i in range(n):
+                name = l.balf_state_tensor_name(i).decode()
+                t = sd[name].detach().to("cpu", torch.float32).contiguous()
+                if t.numel() != l.balf_state_tensor_numel(i):
+                    raise BalfHipError(f"{name}: {t.numel()} elements, library expects {l.balf_state_tensor_numel(i)}")
+                host.append(t)
+            ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in host])
+            prec = self._precision_code()
+            nbytes = l.balf_packed_weights_bytes(prec)
+            if nbytes == 0:
+                raise BalfHipError(f"precision {self.precision!r} is not available in this build of libbalf_hip.so")
+            blob = torch.empty(nbytes, dtype=torch.uint8)
+            check(l.balf_pack_weights(ptrs, n, prec, blob.data_ptr(), nbytes), "balf_pack_weights")
+            self._packed = blob.to(device)
+            self._packed_key = key
+        return self._packed
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, want_logits: bool = True):
+        if self.training:
+            raise BalfHipError("balf_amd implements the inference path only: call .eval() first "
+                               "(training, /root/reference/balf/utils/train_utils.py:79-160, is out of scope)")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected [B,3,H,W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise BalfHipError("balf_amd has no CPU path: move the model and the input to the GPU")
+        b, _, h, w = x.shape
+        if h % 64 or w % 64:
+            raise ValueError(f"H and W must be multiples of 64 (pad with mod_padding_symmetric), got {h}x{w}")
+        x = x.contiguous().float()
+        dev = x.device
+        l = lib()
+        blob = self.packed_weights(dev)
+        prob = torch.empty((b, h, w), dtype=torch.float32, device=dev)
+        logits = torch.empty((b, 65, h // 8, w // 8), dtype=torch.float32, device=dev) if want_logits else None
+        nbytes = l.balf_forward_workspace_bytes(b, h, w)
+        ws = ops._workspace("forward", dev, nbytes)
+        with torch.cuda.device(dev):
+            check(l.balf_forward(blob.data_ptr(), self._precision_code(), x.data_ptr(), b, h, w,
+                                 logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), _lib.current_stream_ptr(dev)), "balf_forward")
+        return {"logits": logits, "prob": prob}

@@ -1,0 +1,66 @@
+"""Thin torch-tensor wrappers over the C ABI (device memory and streams are PyTorch's; the compute
+is the HIP library's).  Every function requires CUDA tensors and raises otherwise."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BalfHipError, check, current_stream_ptr, lib, require_gpu_tensor
+
+_workspaces: Dict[Tuple[str, int], torch.Tensor] = {}
+
+
+def _workspace(tag: str, device, nbytes: int) -> torch.Tensor:
+    """Caller-owned scratch, cached per device and grown on demand (the library never allocates)."""
+    key = (tag, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def release_workspaces() -> None:
+    _workspaces.clear()
+
+
+def window_nms(score: torch.Tensor, border: int, nms_size: int) -> torch.Tensor:
+    """[B,H,W] fp32 -> dense apply_nms(remove_borders(score, border), nms_size)
+    (/root/reference/balf/utils/test_utils.py:34-54)."""
+    require_gpu_tensor(score, "score")
+    if score.dtype != torch.float32 or score.dim() != 3:
+        raise BalfHipError("score must be a [B,H,W] float32 tensor")
+    out = torch.empty_like(score)
+    b, h, w = score.shape
+    with torch.cuda.device(score.device):
+        check(lib().balf_window_nms(score.data_ptr(), b, h, w, int(border), int(nms_size), out.data_ptr(),
+                                    current_stream_ptr(score.device)), "balf_window_nms")
+    return out
+
+
+def nms_topk(prob: torch.Tensor, crop_y: int, crop_x: int, h: int, w: int, border: int, nms_size: int,
+             k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """[B,Hp,Wp] fp32 score maps -> (idx [B,K] int32, score [B,K] fp32, count [B] int32); see
+    balf_nms_topk in include/balf_hip.h.  ``k > h*w`` raises IndexError like the reference
+    (/root/reference/balf/utils/test_utils.py:83)."""
+    require_gpu_tensor(prob, "prob")
+    if prob.dtype != torch.float32 or prob.dim() != 3:
+        raise BalfHipError("prob must be a [B,Hp,Wp] float32 tensor")
+    if k > h * w:
+        raise IndexError(f"index {k - 1} is out of bounds for axis 0 with size {h * w}")
+    b, hp, wp = prob.shape
+    dev = prob.device
+    idx = torch.empty((b, k), dtype=torch.int32, device=dev)
+    score = torch.empty((b, k), dtype=torch.float32, device=dev)
+    count = torch.empty((b,), dtype=torch.int32, device=dev)
+    nbytes = lib().balf_nms_topk_workspace_bytes(b, h, w, k)
+    ws = _workspace("nms", dev, nbytes)
+    with torch.cuda.device(dev):
+        check(lib().balf_nms_topk(prob.data_ptr(), b, hp, wp, int(crop_y), int(crop_x), int(h), int(w),
+                                  int(border), int(nms_size), int(k), idx.data_ptr(), score.data_ptr(),
+                                  count.data_ptr(), ws.data_ptr(), ws.numel(), current_stream_ptr(dev)),
+              "balf_nms_topk")
+    return idx, score, count

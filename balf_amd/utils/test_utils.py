@@ -1,0 +1,90 @@
+"""Host-side mirror of the reference's inference helpers, backed by the HIP library.
+
+Same names, argument meaning and error behaviour as /root/reference/balf/utils/test_utils.py
+(``make_shape_even:16``, ``mod_padding_symmetric:23``, ``remove_borders:34``, ``apply_nms:50``,
+``get_point_coordinates:56``, ``find_index_higher_scores:74``) so callers such as
+``train_utils.extract_detections`` (/root/reference/balf/utils/train_utils.py:416-454) can import
+this module instead.  NumPy arrays in, NumPy arrays out; the window-max NMS and the top-K selection
+run on the GPU and there is no CPU fallback -- without a GPU these functions raise.
+The pad/border helpers only move bytes and stay on the host, as in the reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import yaml
+
+from .. import ops
+from .._lib import BalfHipError
+
+
+def get_cfg_from_yaml_file(cfg_file):
+    with open(cfg_file, "r") as f:
+        return yaml.load(f, Loader=yaml.FullLoader)
+
+
+def make_shape_even(image):
+    h, w = image.shape[0], image.shape[1]
+    return np.pad(image, ((0, h % 2), (0, w % 2), (0, 0)), mode="constant", constant_values=0)
+
+
+def mod_padding_symmetric(image, factor=64):
+    h, w = image.shape[0], image.shape[1]
+    ph = (h // factor + 1) * factor - h if h % factor != 0 else 0
+    pw = (w // factor + 1) * factor - w if w % factor != 0 else 0
+    return np.pad(image, ((ph // 2, ph // 2), (pw // 2, pw // 2), (0, 0)), mode="constant", constant_values=0)
+
+
+def remove_borders(image, borders):
+    out = np.zeros_like(image)
+    h, w = image.shape[0], image.shape[1]
+    out[borders:h - borders, borders:w - borders] = image[borders:h - borders, borders:w - borders]
+    return out
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise BalfHipError("no GPU visible: balf_amd.utils.test_utils has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _as_map(score_map) -> np.ndarray:
+    m = np.ascontiguousarray(score_map, dtype=np.float32)
+    if m.ndim != 2:
+        raise ValueError("score map must be [H, W]")
+    return m
+
+
+def apply_nms(score_map, size):
+    m = _as_map(score_map)
+    t = torch.from_numpy(m).to(_device()).unsqueeze(0)
+    return ops.window_nms(t, 0, int(size))[0].cpu().numpy()
+
+
+def find_index_higher_scores(map, num_points=1000, threshold=-1):
+    """[row, col] pairs, in raster order, of the first ``num_points`` pixels whose value reaches the
+    ``num_points``-th largest value of the map (with the reference's <= 0 fallback)."""
+    if threshold != -1:
+        raise NotImplementedError("explicit thresholds are not on the accelerated path (threshold=-1 only)")
+    m = _as_map(map)
+    h, w = m.shape
+    t = torch.from_numpy(m).to(_device()).unsqueeze(0)
+    # a 1x1 window keeps every pixel, so this is the K-th-threshold selection alone
+    idx, _, cnt = ops.nms_topk(t, 0, 0, h, w, 0, 1, int(num_points))
+    flat = np.sort(idx[0, : int(cnt[0])].cpu().numpy().astype(np.int64))
+    return np.stack([flat // w, flat % w], axis=1)
+
+
+def get_point_coordinates(map, scale_value=1., num_points=1000, threshold=-1, order_coord='xysr'):
+    m = _as_map(map)
+    ind = find_index_higher_scores(m, num_points=num_points, threshold=threshold)
+    sc = m[ind[:, 0], ind[:, 1]].astype(np.float64)
+    out = np.empty((ind.shape[0], 4), dtype=np.float64)
+    if order_coord == 'xysr':
+        out[:, 0], out[:, 1] = ind[:, 1], ind[:, 0]
+    elif order_coord == 'yxsr':
+        out[:, 0], out[:, 1] = ind[:, 0], ind[:, 1]
+    else:
+        raise ValueError(order_coord)
+    out[:, 2], out[:, 3] = scale_value, sc
+    return out

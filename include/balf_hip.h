@@ -1,0 +1,100 @@
+/*
+ * balf_hip.h -- C ABI of libbalf_hip.so: the MI355X (gfx950) implementation of BALF's
+ * keypoint-detection hot path (detector forward -> score map -> window-max NMS -> top-K).
+ *
+ * The reference is pure Python and has no FFI of its own; these entry points
+ * are what a binding for this path replaces, one per reference call site:
+ *
+ *   balf_pack_weights        <- MLP_MA_DECODER.load_state_dict, reached from
+ *                               balf/model/get_model.py:65-67 (load_test_pretrained_model)
+ *   balf_forward             <- MLP_MA_DECODER.forward, balf/model/mlp_ma_decoder.py:278-285
+ *                               (+ DetectorHead.forward, balf/model/decoder.py:16-30)
+ *   balf_window_nms          <- remove_borders + apply_nms, balf/utils/test_utils.py:34-54
+ *   balf_nms_topk            <- crop + remove_borders + apply_nms + get_point_coordinates /
+ *                               find_index_higher_scores + final sort,
+ *                               balf/utils/train_utils.py:437-452, balf/utils/test_utils.py:50-95
+ *
+ * Conventions: plain pointers and sizes only.  Every device buffer (inputs, outputs, workspace)
+ * is owned by the caller; the library never allocates or frees device memory, never calls
+ * hipDeviceSynchronize, and enqueues all work on the hipStream_t passed as `stream`
+ * (as void*; NULL = the null stream).  Every function returns BALF_OK (0) or a negative
+ * BALF_ERR_* code and never throws.  Shapes are validated on the host before any launch.
+ */
+#ifndef BALF_HIP_H
+#define BALF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BALF_ABI_VERSION 1
+
+#define BALF_OK 0
+#define BALF_ERR_ARG (-1)        /* null pointer, non-positive size, unsupported parameter        */
+#define BALF_ERR_SHAPE (-2)      /* H/W not a multiple of 64, crop outside the padded map, K > H*W */
+#define BALF_ERR_WORKSPACE (-3)  /* workspace smaller than *_workspace_bytes() says               */
+#define BALF_ERR_ARCH (-4)       /* current device is not gfx950                                  */
+#define BALF_ERR_LAUNCH (-5)     /* HIP reported an error at launch                               */
+
+/* limits */
+#define BALF_MAX_NMS_SIZE 32     /* window-max NMS footprint side (reference default 15)          */
+#define BALF_MAX_TOPK 16384      /* num_points per image (reference configs use 1000..10000)      */
+
+/* precision of the Linear-layer contractions (everything else is always fp32) */
+#define BALF_PREC_FP32 0         /* v_mfma_f32_16x16x4_f32, exact fp32 fma chains                  */
+#define BALF_PREC_FP16 1         /* v_mfma_f32_16x16x32_f16, fp16 operands, fp32 accumulate        */
+
+int balf_abi_version(void);
+const char *balf_error_string(int code);
+/* BALF_OK iff the current HIP device is a gfx950 part. */
+int balf_device_check(void);
+
+/* ---- weights ------------------------------------------------------------------------------
+ * The 166 floating-point state-dict tensors of MLP_MA_DECODER in state_dict() order
+ * (num_batches_tracked, the one int64 entry, is skipped).  balf_state_tensor_name/numel let a
+ * binding check its table against the library's.  balf_pack_weights runs on the HOST: it
+ * reads `n_tensors` host pointers (contiguous fp32, nn.Linear layout [out,in]) and writes the
+ * packed blob (MFMA-fragment-ordered weights, BatchNorm folded into the head) that the caller
+ * then copies to the device and passes to balf_forward as `packed_dev`. */
+int balf_num_state_tensors(void);
+const char *balf_state_tensor_name(int i);
+size_t balf_state_tensor_numel(int i);
+size_t balf_packed_weights_bytes(int precision);
+int balf_pack_weights(const float *const *tensors, int n_tensors, int precision,
+                      void *packed_host, size_t packed_bytes);
+
+/* ---- detector forward ---------------------------------------------------------------------
+ * x_nchw_dev : [B,3,Hp,Wp] fp32, Hp and Wp multiples of 64 (callers pad: test_utils.py:23-32)
+ * logits_dev : [B,65,Hp/8,Wp/8] fp32 (post-BatchNorm, pre-softmax), may be NULL to skip
+ * prob_dev   : [B,Hp,Wp] fp32 score map (softmax over 65, dustbin dropped, pixel-shuffled)
+ * workspace  : balf_forward_workspace_bytes(B,Hp,Wp) bytes, 256-byte aligned */
+size_t balf_forward_workspace_bytes(int B, int Hp, int Wp);
+int balf_forward(const void *packed_dev, int precision, const float *x_nchw_dev, int B, int Hp, int Wp,
+                 float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
+                 void *stream);
+
+/* ---- window-max NMS, dense form (apply_nms) ------------------------------------------------
+ * score_dev [B,H,W] fp32 -> out_dev [B,H,W] fp32 = rb * (rb == max over the clipped
+ * nms_size x nms_size window), rb = score with a `border`-pixel frame zeroed. */
+int balf_window_nms(const float *score_dev, int B, int H, int W, int border, int nms_size,
+                    float *out_dev, void *stream);
+
+/* ---- crop + border + NMS + exact top-K ------------------------------------------------------
+ * prob_dev [B,Hp,Wp]; the score map of image b is prob[b, crop_y:crop_y+H, crop_x:crop_x+W].
+ * Outputs per image: idx_dev[b,0:count] flat indices y*W+x of the first K pixels in raster
+ * order whose NMS score >= the K-th largest NMS score (reference fallback when that is <= 0),
+ * emitted sorted by (score descending, index ascending); score_dev their scores;
+ * entries past count are idx -1 / score 0.  K <= H*W (the reference raises IndexError
+ * otherwise) and K <= BALF_MAX_TOPK. */
+size_t balf_nms_topk_workspace_bytes(int B, int H, int W, int K);
+int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W,
+                  int border, int nms_size, int K, int32_t *idx_dev, float *score_dev,
+                  int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BALF_HIP_H */
