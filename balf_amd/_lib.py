@@ -32,6 +32,10 @@ PROTOTYPES = {
     "balf_window_nms": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp]),
     "balf_nms_topk_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "balf_nms_topk": (_i, [_fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _fp, _vp, _vp, _sz, _vp]),
+    "balf_profile_num_slots": (_i, []),
+    "balf_profile_slot_name": (C.c_char_p, [_i]),
+    "balf_profile_begin": (_i, []),
+    "balf_profile_end": (_i, [_vp, _vp]),
 }
 
 

@@ -26,6 +26,7 @@
 //   head_kernel      stage 4: x2 -> conv2 -> relu -> dense(256->65) -> BN -> softmax -> pixel shuffle
 #include "common.h"
 #include "layout.h"
+#include "prof.h"
 
 namespace {
 
@@ -561,7 +562,7 @@ struct Plan {
 Plan make_plan(int B, int Hp, int Wp) {
     Plan p{};
     const long px = (long)Hp * Wp;
-    long mb = (16L * 1024 * 1024 + px - 1) / px;       // ~16.8 Mpx of stage-1 activations in flight
+    long mb = (16L * 1024 * 1024) / px;                // <= 16.8 Mpx of stage-1 activations in flight
     if (mb < 1) mb = 1;
     if (mb > B) mb = B;
     p.mb = (int)mb;
@@ -597,20 +598,23 @@ int run_stage(const float *blob, int s, const float *X, int B, int H, int W, flo
                 hipSuccess)
             return BALF_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(k0, dim3(nwg), dim3(256), lds, st, a);
-    hipLaunchKernelGGL(k1, dim3(nwg), dim3(256), lds, st, a);
-    hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], partial, per_img,
-                       1.0f / ((float)H * (float)W), scale);
+    BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(k0, dim3(nwg), dim3(256), lds, st, a));
+    BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(k1, dim3(nwg), dim3(256), lds, st, a));
+    BALF_PROF(4 * s + 2, st,
+              hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], partial, per_img,
+                                 1.0f / ((float)H * (float)W), scale));
     BALF_LAUNCH_CHECK();
     return BALF_OK;
 }
 
 template <int C>
-int run_pool(const float *T, const float *R, const float *scale, int B, int H, int W, float *out, hipStream_t st) {
+int run_pool(int s, const float *T, const float *R, const float *scale, int B, int H, int W, float *out,
+             hipStream_t st) {
     const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(pool_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, st, T, R, scale, B, H, W, out);
+    BALF_PROF(4 * s + 3, st,
+              hipLaunchKernelGGL(pool_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, st, T, R, scale, B, H, W, out));
     BALF_LAUNCH_CHECK();
     return BALF_OK;
 }
@@ -647,17 +651,18 @@ extern "C" int balf_forward(const void *packed_dev, int precision, const float *
         const float *x = x_nchw_dev + (size_t)b0 * 3 * Hp * Wp;
         int rc;
         if ((rc = run_stage<32, 3>(blob, 0, x, nb, Hp, Wp, U, T, R, partial, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_pool<32>(T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
+        if ((rc = run_pool<32>(0, T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
         if ((rc = run_stage<64, 32>(blob, 1, X2, nb, Hp / 2, Wp / 2, U, T, R, partial, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_pool<64>(T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
+        if ((rc = run_pool<64>(1, T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
         if ((rc = run_stage<128, 64>(blob, 2, X3, nb, Hp / 4, Wp / 4, U, T, R, partial, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_pool<128>(T, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
+        if ((rc = run_pool<128>(2, T, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
         if ((rc = run_stage<256, 128>(blob, 3, X4, nb, h8, w8, U, T, R, partial, scale, st)) != BALF_OK) return rc;
         HeadArgs ha{blob, kLayout.st[3], kLayout.head_w, kLayout.head_b, kLayout.head_alpha, kLayout.head_beta,
                     T, R, scale, nb, h8, w8,
                     logits_dev ? logits_dev + (size_t)b0 * kHeadN * h8 * w8 : nullptr,
                     prob_dev + (size_t)b0 * Hp * Wp};
-        hipLaunchKernelGGL(head_kernel, dim3((unsigned)((long)nb * h8 * w8 / 64)), dim3(256), 0, st, ha);
+        BALF_PROF(15, st,
+                  hipLaunchKernelGGL(head_kernel, dim3((unsigned)((long)nb * h8 * w8 / 64)), dim3(256), 0, st, ha));
         BALF_LAUNCH_CHECK();
     }
     return BALF_OK;

@@ -19,6 +19,7 @@
 //                          raster-first K of them (as the reference does); LDS bitonic sort of the
 //                          <= K selected (score desc, index asc) and the padded output rows.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -353,12 +354,14 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const int2 *su
 
 int launch_nms_tiles(const NmsArgs &a, int B, hipStream_t stream) {
     dim3 grid(balf_ceil_div(a.W, TW), balf_ceil_div(a.H, TH), B), block(NTHREADS);
+    if (balf_prof::g_on) balf_prof::before(balf_prof::kNmsTile, stream);
     switch (a.size) {
         case 15: hipLaunchKernelGGL(nms_tile_kernel<15>, grid, block, 0, stream, a); break;
         case 5: hipLaunchKernelGGL(nms_tile_kernel<5>, grid, block, 0, stream, a); break;
         case 3: hipLaunchKernelGGL(nms_tile_kernel<3>, grid, block, 0, stream, a); break;
         default: hipLaunchKernelGGL(nms_tile_kernel_generic, grid, block, 0, stream, a); break;
     }
+    if (balf_prof::g_on) balf_prof::after(stream);
     BALF_LAUNCH_CHECK();
     return BALF_OK;
 }
@@ -413,8 +416,9 @@ extern "C" int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int c
         hipFuncSetAttribute(reinterpret_cast<const void *>(topk_select_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return BALF_ERR_LAUNCH;
-    hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(SEL_THREADS), smem, st, surv, counts, (long)H * W, K,
-                       npow2, idx_dev, score_dev, count_dev);
+    BALF_PROF(balf_prof::kTopkSelect, st,
+              hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(SEL_THREADS), smem, st, surv, counts, (long)H * W,
+                                 K, npow2, idx_dev, score_dev, count_dev));
     BALF_LAUNCH_CHECK();
     return BALF_OK;
 }

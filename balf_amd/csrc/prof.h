@@ -1,0 +1,24 @@
+// Optional per-kernel timing (hipEvent pairs on the launch stream), used by bench.py for the roofline
+// figures.  Off by default; when off a launch costs one predictable branch.  Measurement aid only:
+// global state, not re-entrant.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace balf_prof {
+enum Slot {
+    // stage s in 0..3: 4*s + {0 grid branch, 1 block branch, 2 squeeze-excite, 3 pool (stage 4: head)}
+    kNmsTile = 16,
+    kTopkSelect = 17,
+    kNumSlots = 18,
+};
+extern bool g_on;
+void before(int slot, hipStream_t st);
+void after(hipStream_t st);
+}  // namespace balf_prof
+
+#define BALF_PROF(slot, stream, launch_stmt)                       \
+    do {                                                           \
+        if (balf_prof::g_on) balf_prof::before((slot), (stream));  \
+        launch_stmt;                                               \
+        if (balf_prof::g_on) balf_prof::after((stream));           \
+    } while (0)

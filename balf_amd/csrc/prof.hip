@@ -1,0 +1,80 @@
+#include "prof.h"
+
+#include <vector>
+
+#include "common.h"
+
+namespace balf_prof {
+
+bool g_on = false;
+
+namespace {
+struct Rec { int slot; hipEvent_t a, b; };
+std::vector<hipEvent_t> g_pool;     // created once, reused
+size_t g_used = 0;
+std::vector<Rec> g_recs;
+hipEvent_t g_pending = nullptr;
+int g_pending_slot = -1;
+
+hipEvent_t take_event() {
+    if (g_used == g_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_pool.push_back(e);
+    }
+    return g_pool[g_used++];
+}
+}  // namespace
+
+void before(int slot, hipStream_t st) {
+    g_pending = take_event();
+    g_pending_slot = slot;
+    if (g_pending) (void)hipEventRecord(g_pending, st);
+}
+
+void after(hipStream_t st) {
+    hipEvent_t e = take_event();
+    if (!g_pending || !e) return;
+    (void)hipEventRecord(e, st);
+    g_recs.push_back({g_pending_slot, g_pending, e});
+    g_pending = nullptr;
+}
+
+}  // namespace balf_prof
+
+static const char *kSlotNames[balf_prof::kNumSlots] = {
+    "stage1_grid_branch", "stage1_block_branch", "stage1_se", "stage1_pool",
+    "stage2_grid_branch", "stage2_block_branch", "stage2_se", "stage2_pool",
+    "stage3_grid_branch", "stage3_block_branch", "stage3_se", "stage3_pool",
+    "stage4_grid_branch", "stage4_block_branch", "stage4_se", "stage4_head",
+    "nms_tile", "topk_select"};
+
+extern "C" int balf_profile_num_slots(void) { return balf_prof::kNumSlots; }
+
+extern "C" const char *balf_profile_slot_name(int slot) {
+    return (slot >= 0 && slot < balf_prof::kNumSlots) ? kSlotNames[slot] : nullptr;
+}
+
+extern "C" int balf_profile_begin(void) {
+    balf_prof::g_recs.clear();
+    balf_prof::g_used = 0;
+    balf_prof::g_on = true;
+    return BALF_OK;
+}
+
+extern "C" int balf_profile_end(float *ms_total, int *launches) {
+    using namespace balf_prof;
+    g_on = false;
+    if (!ms_total || !launches) return BALF_ERR_ARG;
+    for (int i = 0; i < kNumSlots; ++i) { ms_total[i] = 0.0f; launches[i] = 0; }
+    for (const Rec &r : g_recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) return BALF_ERR_LAUNCH;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return BALF_ERR_LAUNCH;
+        ms_total[r.slot] += ms;
+        launches[r.slot] += 1;
+    }
+    g_recs.clear();
+    g_used = 0;
+    return BALF_OK;
+}

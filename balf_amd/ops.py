@@ -64,3 +64,17 @@ def nms_topk(prob: torch.Tensor, crop_y: int, crop_x: int, h: int, w: int, borde
                                   count.data_ptr(), ws.data_ptr(), ws.numel(), current_stream_ptr(dev)),
               "balf_nms_topk")
     return idx, score, count
+
+
+def profile_begin() -> None:
+    check(lib().balf_profile_begin(), "balf_profile_begin")
+
+
+def profile_end():
+    """-> {slot name: (total device ms, launches)} for the launches since profile_begin()."""
+    l = lib()
+    n = l.balf_profile_num_slots()
+    ms = (C.c_float * n)()
+    cnt = (C.c_int * n)()
+    check(l.balf_profile_end(ms, cnt), "balf_profile_end")
+    return {l.balf_profile_slot_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n) if cnt[i]}

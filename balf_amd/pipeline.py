@@ -1,0 +1,82 @@
+"""The detection pipeline around the model: pad -> forward -> crop/border/NMS/top-K, batched and
+data-parallel.
+
+``extract_detections`` mirrors the reference's canonical caller
+(/root/reference/balf/utils/train_utils.py:416-454): same arguments, same return values
+(``pts_output`` rows ``[x, y, 1.0, score]`` float64 sorted by score, and the cropped score-map
+batch).  ``detect_batch`` is the batched form the benchmark drives: everything stays on the GPU and
+only ``[B, K]`` keypoint slabs come out.  ``allgather_keypoints`` is the one collective of the
+multi-GPU path: images are independent, so ranks shard the batch and exchange
+nothing but their fixed-size keypoint slabs (RCCL all-gather over xGMI; gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import arch, ops
+from .utils import test_utils as T
+
+
+def detect_batch(model, x_pad: torch.Tensor, h: int, w: int, border: int = 15, nms_size: int = 15,
+                 num_points: int = 1000, precomputed_offsets: Optional[Tuple[int, int]] = None):
+    """x_pad [B,3,Hp,Wp] (already padded as ``mod_padding_symmetric`` does) -> (idx [B,K] int32 flat
+    ``y*w+x`` in un-padded coordinates, score [B,K] fp32, count [B] int32, prob [B,Hp,Wp])."""
+    hp, wp = x_pad.shape[-2:]
+    if precomputed_offsets is None:
+        ehp, ewp, top, left = arch.padded_hw(h, w)
+        if (ehp, ewp) != (hp, wp):
+            raise ValueError(f"a {h}x{w} image pads to {ehp}x{ewp}, got {hp}x{wp}")
+    else:
+        top, left = precomputed_offsets
+    prob = model(x_pad, want_logits=False)["prob"]
+    idx, score, count = ops.nms_topk(prob, top, left, h, w, border, nms_size, num_points)
+    return idx, score, count, prob
+
+
+def pad_batch(images_rgb_norm: np.ndarray) -> torch.Tensor:
+    """[B,H,W,3] float in [0,1] -> padded [B,3,Hp,Wp] float32 CPU tensor (make_shape_even +
+    mod_padding_symmetric, test_utils.py:16-32; torch.tensor(...).permute, train_utils.py:426-428)."""
+    out = [T.mod_padding_symmetric(T.make_shape_even(im), factor=64) for im in images_rgb_norm]
+    return torch.from_numpy(np.stack(out).astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+
+
+@torch.no_grad()
+def extract_detections(image_RGB_norm, model, device, cell_size=8, nms_size=15, num_points=25, border_size=15):
+    h, w = image_RGB_norm.shape[0], image_RGB_norm.shape[1]
+    x = pad_batch(image_RGB_norm[None]).to(device)
+    idx, score, count, prob = detect_batch(model, x, h, w, border_size, nms_size, num_points)
+    n = int(count[0])
+    i = idx[0, :n].cpu().numpy().astype(np.int64)
+    pts = np.empty((n, 4), dtype=np.float64)
+    pts[:, 0], pts[:, 1], pts[:, 2], pts[:, 3] = i % w, i // w, 1.0, score[0, :n].cpu().numpy()
+    _, _, top, left = arch.padded_hw(h, w)
+    return pts, prob[:, top:top + h, left:left + w].unsqueeze(1)
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split of ``total`` images: rank r gets [lo, hi)."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def allgather_keypoints(idx: torch.Tensor, score: torch.Tensor, count: torch.Tensor, group=None):
+    """Every rank ends up with the keypoints of the whole batch, in rank order.  Slabs have the same
+    shape on every rank (equal shards; pad with ``-1`` rows otherwise)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return idx, score, count
+    world = dist.get_world_size(group)
+    b, k = idx.shape
+    # one slab per rank: [B, K] indices, [B, K] score bits and [B] counts, packed as int32 so that the
+    # step costs a single latency-bound collective
+    slab = torch.empty((b, 2 * k + 1), dtype=torch.int32, device=idx.device)
+    slab[:, :k] = idx
+    slab[:, k:2 * k] = score.view(torch.int32)
+    slab[:, 2 * k] = count
+    out = torch.empty((world * b, 2 * k + 1), dtype=torch.int32, device=idx.device)
+    dist.all_gather_into_tensor(out, slab, group=group)
+    return out[:, :k].contiguous(), out[:, k:2 * k].contiguous().view(torch.float32), out[:, 2 * k].contiguous()

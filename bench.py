@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the BALF keypoint-detection hot path on MI355X.
+
+One step = one pass of the hot path (detector forward -> score map -> crop/border/window-max NMS ->
+exact top-K -> all-gather of keypoint slabs when N > 1) over one per-GPU batch of synthetic 1080p
+grayscale images already resident in HBM (gray replicated to 3 channels, /255, padded to 1088x1920:
+SURVEY.md F4/F5).  Workload = BASELINE.json configs[3] divided over the node: 32 images per GPU
+(256 over 8 GPUs), top-2000, border 15, nms 15; weak scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|fp16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` = images/s over all GPUs; `keypoints_per_s` rides along.
+`roofline` is for the dominant kernel (per-kernel device time from hipEvent pairs on the launch
+stream over the timed steps: balf_profile_begin/end in include/balf_hip.h); `cpu_baseline` times the
+CPU oracle (a port of the reference path, oracle/) on a bounded sample on rank 0 at N = 1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from balf_amd import arch, ops, pipeline  # noqa: E402
+from balf_amd.model import get_model  # noqa: E402
+from balf_amd.utils import synth  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, dense f32 MFMA
+PEAK_FP16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def stage_macs_per_pixel(s: int):
+    """Algorithmic MACs per stage-resolution pixel of the two branch kernels:
+    grid kernel = u half of dense1 + grid gMLP; block kernel = conv0 + v half + block gMLP + dense2 +
+    RCAB convs.  Recomputed work (x0 and LN in the grid kernel) is not counted."""
+    c = [32, 64, 128, 256][s]
+    cin = [3, 32, 64, 128][s]
+    grid = c * c + 2 * c * c + 64 * c + c * c
+    block = cin * c + c * c + 2 * c * c + 64 * c + c * c + 2 * c * c + c * c + c * c
+    return grid, block
+
+
+def kernel_flops_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
+    if name.startswith("stage") and ("grid_branch" in name or "block_branch" in name):
+        s = int(name[5]) - 1
+        g, b = stage_macs_per_pixel(s)
+        px = mb * (hp >> s) * (wp >> s)
+        return 2.0 * (g if "grid" in name else b) * px
+    if name == "stage4_head":
+        return 2.0 * (256 * 256 + 256 * 65) * mb * (hp // 8) * (wp // 8)
+    return 0.0
+
+
+def cpu_baseline(h, w, k, n_images, state):
+    """The CPU oracle (port of the reference path) on `n_images` of the same workload."""
+    from oracle import oracle as O
+    from oracle import c_oracle
+    torch.set_num_threads(os.cpu_count() or 1)
+    imgs = np.stack([synth.gray_to_rgb_norm(synth.synthetic_gray_u8(h, w, i)) for i in range(n_images)])
+    t0 = time.perf_counter()
+    kp = 0
+    with torch.no_grad():
+        for i in range(n_images):
+            pad = O.mod_padding_symmetric(O.make_shape_even(imgs[i]), 64)
+            x = torch.tensor(pad, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0)
+            prob = O.detector_forward(state, x)["prob"][0].numpy()
+            top, left = O.crop_offsets(h, w, *prob.shape)
+            idx, sc, _ = c_oracle.nms_topk(prob[top:top + h, left:left + w], 15, 15, k)
+            kp += idx.size
+    dt = time.perf_counter() - t0
+    return {"value": n_images / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "keypoints_per_s": kp / dt,
+            "sample": f"{n_images} synthetic {w}x{h} gray images, batch 1, oracle forward (torch CPU fp32) + C NMS/top-{k}; "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--batch-per-gpu", type=int, default=32)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--topk", type=int, default=2000)
+    ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: balf_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+
+    h, w, k, b = args.height, args.width, args.topk, args.batch_per_gpu
+    hp, wp, top, left = arch.padded_hw(h, w)
+    state = synth.synthetic_state_dict(20240)
+    model = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    model.load_state_dict(state)
+    model.precision = args.precision
+    model = model.eval().to(dev)
+
+    # synthetic inputs, resident in HBM before the timed region: this rank's shard of the global batch
+    lo = rank * b
+    gray = np.stack([synth.synthetic_gray_u8(h, w, lo + i, blur=5 if i % 2 == 0 else 1) for i in range(b)])
+    g = torch.from_numpy(gray).to(dev).float().div_(255.0)
+    x = torch.zeros((b, 3, hp, wp), dtype=torch.float32, device=dev)
+    x[:, :, top:top + h, left:left + w] = g[:, None]
+    del g
+
+    def step():
+        idx, score, count, _ = pipeline.detect_batch(model, x, h, w, 15, 15, k, precomputed_offsets=(top, left))
+        return pipeline.allgather_keypoints(idx, score, count)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    ops.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_end()
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    counts = out[2]
+    kp_per_image = float(counts.float().mean().item())
+
+    if rank == 0:
+        images = world * b * args.steps
+        ips = images / dt
+        # dominant kernel by device time
+        name, (ms, n_launch) = max(prof.items(), key=lambda kv: kv[1][0])
+        mb = max(1, min(b, 16 * 1024 * 1024 // (hp * wp)))      # images per launch (make_plan in detector.hip)
+        launches_per_step = -(-b // mb)
+        avg_ms = ms / n_launch
+        flops = kernel_flops_per_launch(name, mb, hp, wp)
+        peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_FP16_MFMA_TFLOPS
+        achieved = flops / (avg_ms * 1e-3) / 1e12 if flops else 0.0
+        fwd_ms = sum(v[0] for kname, v in prof.items() if kname.startswith("stage")) / args.steps
+        nms_ms = sum(v[0] for kname, v in prof.items() if not kname.startswith("stage")) / args.steps
+        nms_bytes = b * (4.0 * h * w + 8.0 * k + 4.0)
+        res = {
+            "metric": "images/sec + keypoints/sec on 1080p gray (detector forward + NMS + top-K)",
+            "value": ips, "unit": "images/s", "keypoints_per_s": ips * kp_per_image,
+            "keypoints_per_image": kp_per_image,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f16 MFMA operands, f32 accumulate/LN/GELU/softmax/NMS",
+            "data": "synthetic",
+            "config": {"workload": f"{b} images/GPU x {world} GPU, {w}x{h} gray -> [B,3,{hp},{wp}] fp32, top-{k}, "
+                                   f"border 15, nms 15 (BASELINE configs[3] shard)",
+                       "global_batch": b * world, "parallelism": f"dp{world}",
+                       "collective": "all_gather of [B,2K+1] int32 keypoint slabs" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": n_launch, "images_per_launch": mb,
+                         "algorithmic_flop_per_launch": flops},
+            "forward_device_ms_per_step": fwd_ms, "nms_topk_device_ms_per_step": nms_ms,
+            "forward_tflops": b * hp * wp * arch.FLOP_PER_PADDED_PIXEL / (fwd_ms * 1e-3) / 1e12,
+            "forward_frac_of_mfma_peak": b * hp * wp * arch.FLOP_PER_PADDED_PIXEL / (fwd_ms * 1e-3) / 1e12 / peak,
+            "nms_topk_roofline": {"bound": "hbm", "achieved": nms_bytes / (nms_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                  "unit": "GB/s", "frac": nms_bytes / (nms_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "kernels_ms_per_step": {kname: v[0] / args.steps for kname, v in sorted(prof.items())},
+        }
+        if world == 1 and args.cpu_images > 0:
+            res["cpu_baseline"] = cpu_baseline(h, w, k, args.cpu_images, state)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,16 @@ int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int 
                   int border, int nms_size, int K, int32_t *idx_dev, float *score_dev,
                   int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* ---- measurement aid (not part of the data path) ---------------------------------------------
+ * Between balf_profile_begin() and balf_profile_end() every kernel launch of the library is bracketed
+ * by a hipEvent pair on its launch stream.  balf_profile_end() waits for those events and returns,
+ * per slot (balf_profile_slot_name), the summed device time in ms and the number of launches.
+ * Global state, not re-entrant; bench.py uses it for the per-kernel roofline figures. */
+int balf_profile_num_slots(void);
+const char *balf_profile_slot_name(int slot);
+int balf_profile_begin(void);
+int balf_profile_end(float *ms_total, int *launches);
+
 #ifdef __cplusplus
 }
 #endif

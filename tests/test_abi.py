@@ -1,0 +1,132 @@
+"""The C-ABI library loads and exports every symbol include/balf_hip.h declares (no compute: CPU only),
+and the host-side entry points that need no GPU behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from balf_amd import _lib, arch
+from balf_amd.utils import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.isfile(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.lib()
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "balf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(balf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = header_functions()
+    assert len(names) >= 15
+    raw = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in balf_hip.h but not exported"
+    assert sorted(_lib.PROTOTYPES) == names, "balf_amd/_lib.py prototypes out of step with the header"
+
+
+def test_version_and_error_strings(lib):
+    assert lib.balf_abi_version() == 1
+    for code in (0, -1, -2, -3, -4, -5):
+        assert lib.balf_error_string(code)
+    assert b"workspace" in lib.balf_error_string(-3)
+
+
+def test_state_table_matches_reference_state_dict(lib):
+    ents = [(n, s) for n, s, d in arch.state_entries() if d == "float32"]
+    assert lib.balf_num_state_tensors() == len(ents) == 166
+    for i, (n, s) in enumerate(ents):
+        assert lib.balf_state_tensor_name(i).decode() == n
+        assert lib.balf_state_tensor_numel(i) == int(np.prod(s))
+    assert lib.balf_state_tensor_name(166) is None
+
+
+def test_size_queries_and_argument_checks(lib):
+    assert lib.balf_forward_workspace_bytes(1, 64, 64) > 0
+    assert lib.balf_forward_workspace_bytes(1, 100, 64) == 0          # not a multiple of 64
+    assert lib.balf_forward_workspace_bytes(32, 1088, 1920) == lib.balf_forward_workspace_bytes(8, 1088, 1920)
+    assert lib.balf_nms_topk_workspace_bytes(2, 480, 640, 1000) >= 2 * 480 * 640 * 8
+    assert lib.balf_packed_weights_bytes(0) >= 1280728 * 4
+    # host-side validation happens before anything touches a device
+    assert lib.balf_forward(None, 0, None, 1, 64, 64, None, None, None, 0, None) == -1
+    assert lib.balf_nms_topk(None, 1, 64, 64, 0, 0, 64, 64, 15, 15, 10, None, None, None, None, 0, None) == -1
+    assert lib.balf_window_nms(None, 1, 8, 8, 0, 3, None, None) == -1
+
+
+def pack(lib, sd):
+    n = lib.balf_num_state_tensors()
+    host = [sd[lib.balf_state_tensor_name(i).decode()].contiguous() for i in range(n)]
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in host])
+    nbytes = lib.balf_packed_weights_bytes(0)
+    blob = np.zeros(nbytes // 4, np.float32)
+    assert lib.balf_pack_weights(ptrs, n, 0, blob.ctypes.data, nbytes) == 0
+    return blob
+
+
+def test_pack_weights_fragment_order(lib):
+    """Every weight element must appear in the blob where layout.h says (A-fragment order)."""
+    sd = synth.synthetic_state_dict(5)
+    blob = pack(lib, sd)
+
+    def frags(wt, npad=None):
+        w = wt.numpy()
+        n, k = w.shape
+        npad = npad or n
+        wp = np.zeros((npad, k), np.float32); wp[:n] = w
+        lane = np.arange(64)
+        out = np.empty((npad // 16, k // 16, 64, 4), np.float32)
+        for nt in range(npad // 16):
+            for kt in range(k // 16):
+                for j in range(4):
+                    out[nt, kt, :, j] = wp[16 * nt + (lane & 15), 16 * kt + 4 * (lane >> 4) + j]
+        return out.ravel()
+
+    def find(sub):
+        """offset of `sub` in the blob (weights are random, so the match is unique)"""
+        first = np.flatnonzero(blob == sub[0])
+        for o in first:
+            if o + sub.size <= blob.size and np.array_equal(blob[o:o + sub.size], sub):
+                return int(o)
+        return -1
+
+    rsh = "residual_split_head_multi_axis_gmlp_layer"
+    offs = []
+    for name, npad in [("down1.conv.0.weight", None), (f"down2.{rsh}.dense1.weight", None),
+                       (f"down3.{rsh}.grid_gmlp_layer.grid_gating_unit.dense.weight", None),
+                       (f"down4.{rsh}.dense2.weight", None), ("down4.conv2.weight", None),
+                       ("detector_head.dense.weight", 80)]:
+        t = sd[name]
+        sub = t.numpy().ravel() if name == "down1.conv.0.weight" else frags(t, npad)
+        o = find(sub)
+        assert o >= 0 and o % 64 == 0, name
+        offs.append(o)
+    assert offs == sorted(offs)                                        # blob follows state-dict order
+    # BatchNorm folded to alpha/beta at the end of the blob
+    g, b = sd["detector_head.norm.weight"].double(), sd["detector_head.norm.bias"].double()
+    m, v = sd["detector_head.norm.running_mean"].double(), sd["detector_head.norm.running_var"].double()
+    alpha = (g / torch.sqrt(v + 1e-5)).float().numpy()
+    beta = (b - m * g / torch.sqrt(v + 1e-5)).float().numpy()
+    assert find(alpha) > offs[-1] and find(beta) > find(alpha)
+
+
+def test_pack_rejects_bad_arguments(lib):
+    assert lib.balf_pack_weights(None, 166, 0, None, 0) == -1
+    sd = synth.synthetic_state_dict(5)
+    n = 166
+    host = [sd[lib.balf_state_tensor_name(i).decode()].contiguous() for i in range(n)]
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in host])
+    small = np.zeros(16, np.float32)
+    assert lib.balf_pack_weights(ptrs, n, 0, small.ctypes.data, small.nbytes) == -3
+    assert lib.balf_pack_weights(ptrs, n - 1, 0, small.ctypes.data, small.nbytes) == -1

@@ -1,0 +1,52 @@
+"""The N > 1 path on CPU: world_size-2 gloo run of the keypoint all-gather (the only collective of the
+data-parallel path; RCCL on the GPU box)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from balf_amd import pipeline
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, b, k, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = pipeline.shard_range(world * b, rank, world)
+        g = torch.Generator().manual_seed(1234)
+        all_idx = torch.randint(0, 1 << 20, (world * b, k), generator=g, dtype=torch.int32)
+        all_sc = torch.rand((world * b, k), generator=g)
+        all_cnt = torch.randint(0, k + 1, (world * b,), generator=g, dtype=torch.int32)
+        idx, sc, cnt = pipeline.allgather_keypoints(all_idx[lo:hi].clone(), all_sc[lo:hi].clone(), all_cnt[lo:hi].clone())
+        ok = torch.equal(idx, all_idx) and torch.equal(sc, all_sc) and torch.equal(cnt, all_cnt)
+        out_q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_keypoints_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 3, 17, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
+
+
+def test_allgather_is_identity_without_process_group():
+    idx = torch.zeros((2, 5), dtype=torch.int32); sc = torch.zeros((2, 5)); cnt = torch.zeros(2, dtype=torch.int32)
+    a, b, c = pipeline.allgather_keypoints(idx, sc, cnt)
+    assert a is idx and b is sc and c is cnt

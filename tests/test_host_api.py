@@ -1,0 +1,142 @@
+"""Host logic behind the drop-in boundary: get_model's load API, error behaviour, padding helpers.
+CPU only; expectations for the loader come from running the reference's own loader
+(tests/golden/geometry.json, written by make_golden.py)."""
+import json
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from balf_amd import arch, pipeline
+from balf_amd._lib import BalfHipError
+from balf_amd.model import get_model
+from balf_amd.utils import synth
+from balf_amd.utils import test_utils as T
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+GEO = json.load(open(os.path.join(G, "geometry.json")))
+
+
+def new_model():
+    return get_model.load_model(arch.DEFAULT_MODEL_CFG)
+
+
+def test_state_dict_is_the_reference_contract():
+    m = new_model()
+    got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+    assert got == GEO["state"]
+    assert sum(p.numel() for p in m.parameters()) == 1280859 - 0
+    assert isinstance(m, torch.nn.Module) and hasattr(m, "eval") and hasattr(m, "named_parameters")
+
+
+def test_load_model_reads_only_network_architecture():
+    cfg = {"name": "whatever", "network_architecture": dict(arch.DEFAULT_ARCH, out_channels=1)}
+    assert len(get_model.load_model(cfg).state_dict()) == 167
+    bad = dict(arch.DEFAULT_ARCH); del bad["cell_size"]
+    with pytest.raises(KeyError):
+        get_model.load_model({"network_architecture": bad})
+    with pytest.raises(NotImplementedError):
+        get_model.load_model({"network_architecture": dict(arch.DEFAULT_ARCH, en_embed_dims=[3, 16, 32, 64, 128])})
+
+
+def test_loader_matches_reference_behaviour(tmp_path, capsys):
+    sd = synth.synthetic_state_dict(7)
+    m = new_model()
+    full = tmp_path / "full.pth"
+    torch.save({"epoch": 12, "repeatability": 0.5, "model_state": sd, "optimizer_state": None}, full)
+    assert list(get_model.load_test_pretrained_model(m, str(full), device="cpu")) == GEO["loader"]["full"]
+    assert float(m.state_dict()["down3.conv2.bias"][5]) == GEO["loader"]["full_probe"]
+    bare = tmp_path / "bare.pth"
+    torch.save({"model_state": sd}, bare)
+    assert list(get_model.load_test_pretrained_model(m, str(bare), device="cpu")) == GEO["loader"]["bare"]
+
+    def attempt(tag, mut):
+        d = dict(sd); mut(d)
+        p = tmp_path / (tag + ".pth")
+        torch.save({"model_state": d}, p)
+        try:
+            get_model.load_test_pretrained_model(m, str(p), device="cpu")
+            return "ok"
+        except AssertionError:
+            return "AssertionError"
+
+    assert attempt("missing_key", lambda d: d.pop("down2.conv2.bias")) == GEO["loader"]["missing_key"]
+    assert "Not updated weight down2.conv2.bias" in capsys.readouterr().out
+    assert attempt("wrong_shape", lambda d: d.__setitem__("down1.conv.0.weight", torch.zeros(32, 4))) == \
+        GEO["loader"]["wrong_shape"]
+    assert attempt("extra_key", lambda d: d.__setitem__("not.a.key", torch.zeros(1))) == GEO["loader"]["extra_key"]
+    with pytest.raises(FileNotFoundError):
+        get_model.load_test_pretrained_model(m, str(tmp_path / "nope.pth"), device="cpu")
+
+
+def test_load_pretrained_model_logs(tmp_path):
+    sd = synth.synthetic_state_dict(8)
+    p = tmp_path / "c.pth"
+    torch.save({"epoch": 3, "model_state": sd}, p)
+    msgs = []
+
+    class L:
+        def info(self, s):
+            msgs.append(s)
+
+    assert get_model.load_pretrained_model(new_model(), str(p), L(), device="cpu") == (3, 0.0)
+    assert any("loaded 167/167" in s for s in msgs) and any(s.startswith("Update weight down1.conv.0.weight") for s in msgs)
+    with pytest.raises(FileNotFoundError):
+        get_model.load_pretrained_model(new_model(), str(tmp_path / "x.pth"), L())
+
+
+def test_optimizer_state_round_trip(tmp_path):
+    m = new_model()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    p = tmp_path / "o.pth"
+    torch.save({"model_state": m.state_dict(), "optimizer_state": opt.state_dict()}, p)
+    opt2 = torch.optim.Adam(new_model().parameters(), lr=5e-2)
+    get_model.load_test_pretrained_model(new_model(), str(p), optimizer=opt2, device="cpu")
+    assert opt2.param_groups[0]["lr"] == 1e-3
+
+
+def test_forward_refuses_cpu_training_and_bad_shapes():
+    m = new_model()
+    with pytest.raises(BalfHipError):                    # train mode: inference path only
+        m(torch.zeros(1, 3, 64, 64))
+    m.eval()
+    with pytest.raises(BalfHipError):                    # no CPU fallback
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 1, 64, 64))
+
+
+def test_padding_helpers_match_reference_geometry():
+    for key, g in GEO["pad"].items():
+        h, w = map(int, key.split("x"))
+        img = np.zeros((h, w, 3)); img[0, 0, 0] = 1.0
+        ev = T.make_shape_even(img)
+        pd = T.mod_padding_symmetric(ev, factor=64)
+        assert list(ev.shape[:2]) == g["even"] and list(pd.shape[:2]) == g["padded"]
+        assert list(np.argwhere(pd[:, :, 0] == 1.0)[0]) == g["origin"]
+        x = pipeline.pad_batch(img[None])
+        assert list(x.shape) == [1, 3] + g["padded"] and x.dtype == torch.float32
+    rb = T.remove_borders(np.ones((40, 50), np.float32), 15)
+    assert np.array_equal(rb, O.remove_borders(np.ones((40, 50), np.float32), 15))
+    assert T.remove_borders(np.ones((20, 50), np.float32), 15).sum() == 0
+
+
+def test_accelerated_helpers_fail_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(BalfHipError):
+        T.apply_nms(np.zeros((8, 8), np.float32), 3)
+    with pytest.raises(BalfHipError):
+        T.get_point_coordinates(np.zeros((8, 8), np.float32), num_points=3)
+
+
+def test_shard_range_partitions_the_batch():
+    for total in (256, 255, 7, 1):
+        for world in (1, 2, 4, 8):
+            spans = [pipeline.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
