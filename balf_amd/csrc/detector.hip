@@ -61,7 +61,21 @@ __device__ __forceinline__ void init_bias(f4 (&t)[NT][P], const float *bias, int
     }
 }
 
-__device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact (erf) GELU, nn.GELU() default (mlp_ma_decoder.py:52,99,126): x * Phi(x), with
+// Phi(-|x|) = 0.5 * erfc(|x| / sqrt 2) from Abramowitz-Stegun 7.1.26 (|erfc error| < 1.5e-7).  Measured
+// max-abs error of the whole expression vs fp64 over [-12, 12]: 4.2e-7 (torch's own fp32 GELU: 1.2e-6).
+// ~14 VALU instructions (one v_rcp_f32, one v_exp_f32) instead of ~35 for 0.5x(1 + erff(x/sqrt 2)).
+__device__ __forceinline__ float gelu1(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
+    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);     // coefficients pre-scaled by 1/2
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float y = p * t * e;                     // Phi(-|x|)
+    return fmaxf(x, 0.0f) - ax * y;                // x >= 0: x(1 - y);  x < 0: x y
+}
 
 template <int NT, int P>
 __device__ __forceinline__ void gelu(f4 (&t)[NT][P]) {
@@ -134,6 +148,34 @@ __device__ __forceinline__ void layernorm(const f4 (&x)[NT][P], f4 (&y)[NT][P], 
     }
 }
 
+// LayerNorm without the affine part: (x - mean) * rstd.  Used where gamma/beta were folded into the
+// weights/bias of the Linear that consumes the result (weights.hip: fold_ln).
+template <int NT, int P>
+__device__ __forceinline__ void layernorm_plain(const f4 (&x)[NT][P], f4 (&y)[NT][P]) {
+    constexpr float inv_c = 1.0f / (16 * NT);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        float s = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) s += (x[nt][p][0] + x[nt][p][1]) + (x[nt][p][2] + x[nt][p][3]);
+        const float mean = quarter_allreduce(s) * inv_c;
+        float v = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = x[nt][p][r] - mean;
+                v = fmaf(d, d, v);
+            }
+        const float rstd = 1.0f / sqrtf(quarter_allreduce(v) * inv_c + kLnEps);
+        const float shift = -mean * rstd;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[nt][p][r] = fmaf(x[nt][p][r], rstd, shift);
+    }
+}
+
 template <int NT, int P>
 __device__ __forceinline__ void store_slot(f4 *slot, const f4 (&t)[NT][P], int lane) {
 #pragma unroll
@@ -151,28 +193,44 @@ __device__ __forceinline__ void store_slot(f4 *slot, const f4 (&t)[NT][P], int l
 template <int NTT, int NT0, int NTC, int P, typename BL>
 __device__ __forceinline__ void gemm_chunk(f4 (&acc)[NTT][P], const f4 *__restrict__ wf, int wnt0, int KTtot,
                                            int kt0, int ktn, int lane, BL bload) {
-    const f4 *wp = wf + ((size_t)(wnt0 + NT0) * KTtot + kt0) * 64 + lane;
-    const int nstride = KTtot * 64;
-    f4 a[NTC];
-#pragma unroll
-    for (int nt = 0; nt < NTC; ++nt) a[nt] = wp[nt * nstride];
-#pragma unroll 2
-    for (int kk = 0; kk < ktn; ++kk) {
-        f4 an[NTC];
-        const int kn = (kk + 1 < ktn) ? (kk + 1) : kk;
-#pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) an[nt] = wp[nt * nstride + kn * 64];
-        f4 b[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) b[p] = bload(kk, p);
+    // uniform byte pointer of weight tile (wnt0 + NT0, kt0) + a 32-bit per-lane offset: lets the compiler
+    // use the SGPR-base form of global_load (no 64-bit VALU address arithmetic per load)
+    const char *wbase = reinterpret_cast<const char *>(wf + ((size_t)(wnt0 + NT0) * KTtot + kt0) * 64);
+    const unsigned lane_off = (unsigned)lane * 16u;
+    const unsigned nstride = (unsigned)KTtot * 1024u;          // bytes between weight row-tiles
+    auto wload = [&](int nt, int kk) {
+        return *reinterpret_cast<const f4 *>(wbase + ((unsigned)nt * nstride + (unsigned)kk * 1024u) + lane_off);
+    };
+    auto compute = [&](const f4 (&a)[NTC], const f4 (&b)[P]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int nt = 0; nt < NTC; ++nt)
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[NT0 + nt][p] = mfma4(a[nt][j], b[p][j], acc[NT0 + nt][p]);
+    };
+    // two register stages (0/1), each loaded one whole compute block ahead of its use; ktn is even
+    f4 a0[NTC], a1[NTC], b0[P], b1[P];
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) a[nt] = an[nt];
+    for (int nt = 0; nt < NTC; ++nt) a0[nt] = wload(nt, 0);
+#pragma unroll
+    for (int p = 0; p < P; ++p) b0[p] = bload(0, p);
+    for (int kk = 0; kk < ktn; kk += 2) {
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) a1[nt] = wload(nt, kk + 1);
+#pragma unroll
+        for (int p = 0; p < P; ++p) b1[p] = bload(kk + 1, p);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = (kk + 2 < ktn) ? kk + 2 : kk;           // last pass re-loads (harmless, uniform)
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) a0[nt] = wload(nt, k2);
+#pragma unroll
+        for (int p = 0; p < P; ++p) b0[p] = bload(k2, p);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -190,7 +248,7 @@ __device__ __forceinline__ void gemm_from(f4 (&acc)[NTT][P], const f4 *__restric
 template <int NTT, int P, typename BL>
 __device__ __forceinline__ void gemm(f4 (&acc)[NTT][P], const float *w, int wnt0, int KTtot, int kt0, int ktn,
                                      int lane, BL bload) {
-    constexpr int CH = (P >= 4) ? 2 : (P == 2 ? 4 : 8);
+    constexpr int CH = (P >= 4) ? 2 : ((P == 2 || NTT <= 16) ? 4 : 8);
     gemm_from<NTT, 0, CH, P>(acc, reinterpret_cast<const f4 *>(w), wnt0, KTtot, kt0, ktn, lane, bload);
 }
 
@@ -279,7 +337,7 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel(S
     // ---- z = GELU(dense1[MODE half](LN(x0))) : u (grid) or v (block) ----
     {
         f4 h[NT][P];
-        layernorm(x0, h, blob + S.qln_g, blob + S.qln_b, q);
+        layernorm_plain(x0, h);                        // q.norm affine folded into dense1
         store_slot(slot, h, lane);
     }
     auto from_slot = [&](int kk, int p) { return slot[(kk * P + p) * 64 + lane]; };
@@ -291,7 +349,7 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel(S
     // ---- gMLP branch on z ----
     {
         f4 h[NT][P];
-        layernorm(z, h, blob + Br.ln_g, blob + Br.ln_b, q);
+        layernorm_plain(z, h);                         // branch .norm affine folded into its dense1
         store_slot(slot, h, lane);
     }
     f4 ga[NT][P];                                      // gate input a = first C outputs of dense1
@@ -371,7 +429,7 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel(S
                 *reinterpret_cast<f4 *>(A.R + pix[p] * C + 16 * nt + 4 * q) = x1[nt][p] + x0[nt][p];
             }
         // ---- t = conv2(lrelu(conv1(LN(x1)))) ----
-        layernorm(x1, x1, blob + S.rln_g, blob + S.rln_b, q);
+        layernorm_plain(x1, x1);                       // RCAB .norm affine folded into conv1
         store_slot(slot, x1, lane);
         f4 m1[NT][P];
         init_bias(m1, blob + S.r1_b, q);
@@ -409,24 +467,41 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel(S
 // ------------------------------------------------------------------------------------------------
 // squeeze-excite: s[n, :] = sigmoid(W2 relu(W0 mean_hw(t) + b0) + b2)   (mlp_ma_decoder.py:166-171)
 // ------------------------------------------------------------------------------------------------
+// Level 1: [B, per_img, C] workgroup sums -> [B, kSeChunks, C] chunk sums (fixed order: deterministic).
+constexpr int kSeChunks = 64;
+
 template <int C>
-__global__ __launch_bounds__(256) void se_kernel(const float *blob, StageOff S, const float *partial, int per_img,
-                                                 float inv_hw, float *scale) {
+__global__ __launch_bounds__(256) void se_reduce_kernel(const float *__restrict__ partial, int per_img,
+                                                        float *__restrict__ chunk) {
     constexpr int PARTS = 256 / C > 0 ? 256 / C : 1;
     __shared__ float s_part[PARTS][C];
-    __shared__ float s_mean[C];
-    __shared__ float s_hid[C / 4];
-    const int n = blockIdx.x;
+    const int n = blockIdx.x / kSeChunks, ch = blockIdx.x % kSeChunks;
+    const int per_chunk = (per_img + kSeChunks - 1) / kSeChunks;
+    const int i0 = ch * per_chunk, i1 = (i0 + per_chunk < per_img) ? i0 + per_chunk : per_img;
     const float *pp = partial + (long)n * per_img * C;
-    for (int c = threadIdx.x % C, part = threadIdx.x / C; part < PARTS; part += PARTS) {   // one pass
+    {
+        const int c = threadIdx.x % C, part = threadIdx.x / C;       // 256 threads = PARTS x C exactly
         float acc = 0.0f;
-        for (int i = part; i < per_img; i += PARTS) acc += pp[(long)i * C + c];
+        for (int i = i0 + part; i < i1; i += PARTS) acc += pp[(long)i * C + c];
         s_part[part][c] = acc;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = 0.0f;
         for (int k = 0; k < PARTS; ++k) acc += s_part[k][c];
+        chunk[((long)n * kSeChunks + ch) * C + c] = acc;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void se_kernel(const float *blob, StageOff S, const float *chunk, float inv_hw,
+                                                 float *scale) {
+    __shared__ float s_mean[C];
+    __shared__ float s_hid[C / 4];
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.0f;
+        for (int k = 0; k < kSeChunks; ++k) acc += chunk[((long)n * kSeChunks + k) * C + c];
         s_mean[c] = acc * inv_hw;
     }
     __syncthreads();
@@ -556,7 +631,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
 // ------------------------------------------------------------------------------------------------
 struct Plan {
     int mb;                 // images per micro-batch
-    size_t off_U, off_T, off_R, off_X[3], off_partial, off_scale, total;
+    size_t off_U, off_T, off_R, off_X[3], off_partial, off_chunk, off_scale, total;
 };
 
 Plan make_plan(int B, int Hp, int Wp) {
@@ -576,6 +651,7 @@ Plan make_plan(int B, int Hp, int Wp) {
     p.off_X[1] = take((size_t)mb * (px / 16) * 64);
     p.off_X[2] = take((size_t)mb * (px / 64) * 128);
     p.off_partial = take((size_t)mb * (px / 64) * 32);  // groups/P * C <= px/64 * 32 for every stage
+    p.off_chunk = take((size_t)mb * kSeChunks * 256);
     p.off_scale = take((size_t)mb * 256);
     p.total = o;
     return p;
@@ -583,7 +659,7 @@ Plan make_plan(int B, int Hp, int Wp) {
 
 template <int C, int CIN>
 int run_stage(const float *blob, int s, const float *X, int B, int H, int W, float *U, float *T, float *R,
-              float *partial, float *scale, hipStream_t st) {
+              float *partial, float *chunk, float *scale, hipStream_t st) {
     constexpr int P = StageP<C>::P;
     constexpr int lds = stage_lds_bytes<C, P>();
     StageArgs a{blob, kLayout.st[s], X, B, H, W, U, T, R, partial};
@@ -600,9 +676,11 @@ int run_stage(const float *blob, int s, const float *X, int B, int H, int W, flo
     }
     BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(k0, dim3(nwg), dim3(256), lds, st, a));
     BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(k1, dim3(nwg), dim3(256), lds, st, a));
-    BALF_PROF(4 * s + 2, st,
-              hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], partial, per_img,
-                                 1.0f / ((float)H * (float)W), scale));
+    BALF_PROF(4 * s + 2, st, {
+        hipLaunchKernelGGL(se_reduce_kernel<C>, dim3(B * kSeChunks), dim3(256), 0, st, partial, per_img, chunk);
+        hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], chunk,
+                           1.0f / ((float)H * (float)W), scale);
+    });
     BALF_LAUNCH_CHECK();
     return BALF_OK;
 }
@@ -641,7 +719,7 @@ extern "C" int balf_forward(const void *packed_dev, int precision, const float *
     char *ws = static_cast<char *>(workspace_dev);
     float *U = reinterpret_cast<float *>(ws + pl.off_U), *T = reinterpret_cast<float *>(ws + pl.off_T),
           *R = reinterpret_cast<float *>(ws + pl.off_R), *partial = reinterpret_cast<float *>(ws + pl.off_partial),
-          *scale = reinterpret_cast<float *>(ws + pl.off_scale);
+          *chunk = reinterpret_cast<float *>(ws + pl.off_chunk), *scale = reinterpret_cast<float *>(ws + pl.off_scale);
     float *X2 = reinterpret_cast<float *>(ws + pl.off_X[0]), *X3 = reinterpret_cast<float *>(ws + pl.off_X[1]),
           *X4 = reinterpret_cast<float *>(ws + pl.off_X[2]);
     const int h8 = Hp / 8, w8 = Wp / 8;
@@ -650,13 +728,13 @@ extern "C" int balf_forward(const void *packed_dev, int precision, const float *
         const int nb = (B - b0 < pl.mb) ? (B - b0) : pl.mb;
         const float *x = x_nchw_dev + (size_t)b0 * 3 * Hp * Wp;
         int rc;
-        if ((rc = run_stage<32, 3>(blob, 0, x, nb, Hp, Wp, U, T, R, partial, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<32, 3>(blob, 0, x, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool<32>(0, T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
-        if ((rc = run_stage<64, 32>(blob, 1, X2, nb, Hp / 2, Wp / 2, U, T, R, partial, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<64, 32>(blob, 1, X2, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool<64>(1, T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
-        if ((rc = run_stage<128, 64>(blob, 2, X3, nb, Hp / 4, Wp / 4, U, T, R, partial, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<128, 64>(blob, 2, X3, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool<128>(2, T, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
-        if ((rc = run_stage<256, 128>(blob, 3, X4, nb, h8, w8, U, T, R, partial, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<256, 128>(blob, 3, X4, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         HeadArgs ha{blob, kLayout.st[3], kLayout.head_w, kLayout.head_b, kLayout.head_alpha, kLayout.head_beta,
                     T, R, scale, nb, h8, w8,
                     logits_dev ? logits_dev + (size_t)b0 * kHeadN * h8 * w8 : nullptr,

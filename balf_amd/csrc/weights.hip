@@ -83,6 +83,23 @@ void pack_frags(float *dst, const float *W, int N, int K, int Npad) {
 
 void copy(float *dst, const float *src, size_t n) { memcpy(dst, src, n * sizeof(float)); }
 
+// LayerNorm(x; gamma, beta) followed by Linear(W, b):  W (n * gamma + beta) + b = (W diag gamma) n + (W beta + b)
+// where n = (x - mean) * rstd.  Folding the affine part into the Linear removes 3 VALU ops per element
+// from the kernels (the f32 MFMA shares its pipe with the VALU, so they are not free).
+void fold_ln(const float *W, const float *b, const float *gamma, const float *beta, int N, int K,
+             std::vector<float> &Wf, std::vector<float> &bf) {
+    Wf.resize((size_t)N * K);
+    bf.resize(N);
+    for (int n = 0; n < N; ++n) {
+        double acc = b[n];
+        for (int k = 0; k < K; ++k) {
+            Wf[(size_t)n * K + k] = W[(size_t)n * K + k] * gamma[k];
+            acc += (double)W[(size_t)n * K + k] * (double)beta[k];
+        }
+        bf[n] = (float)acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int balf_num_state_tensors(void) { return (int)table().size(); }
@@ -120,17 +137,20 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
         if (s == 0) copy(blob + S.conv0_w, t[0], (size_t)C * Cin);
         else pack_frags(blob + S.conv0_w, t[0], C, Cin, C);
         copy(blob + S.conv0_b, t[1], C);
-        copy(blob + S.qln_g, t[2], C);
+        std::vector<float> Wf, bf;
+        copy(blob + S.qln_g, t[2], C);                 // kept for reference; the kernels use the folded form
         copy(blob + S.qln_b, t[3], C);
-        pack_frags(blob + S.q1_w, t[4], 2 * C, C, 2 * C);
-        copy(blob + S.q1_b, t[5], 2 * C);
+        fold_ln(t[4], t[5], t[2], t[3], 2 * C, C, Wf, bf);
+        pack_frags(blob + S.q1_w, Wf.data(), 2 * C, C, 2 * C);
+        copy(blob + S.q1_b, bf.data(), 2 * C);
         for (int b = 0; b < 2; ++b) {
             const BranchOff &B = S.br[b];
             const float *const *u = t + 6 + 10 * b;
             copy(blob + B.ln_g, u[0], C);
             copy(blob + B.ln_b, u[1], C);
-            pack_frags(blob + B.d1_w, u[2], 2 * C, C, 2 * C);
-            copy(blob + B.d1_b, u[3], 2 * C);
+            fold_ln(u[2], u[3], u[0], u[1], 2 * C, C, Wf, bf);
+            pack_frags(blob + B.d1_w, Wf.data(), 2 * C, C, 2 * C);
+            copy(blob + B.d1_b, bf.data(), 2 * C);
             copy(blob + B.gln_g, u[4], C);
             copy(blob + B.gln_b, u[5], C);
             pack_frags(blob + B.mix_w, u[6], kTokens, kTokens, kTokens);
@@ -142,8 +162,9 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
         copy(blob + S.q2_b, t[27], C);
         copy(blob + S.rln_g, t[28], C);
         copy(blob + S.rln_b, t[29], C);
-        pack_frags(blob + S.r1_w, t[30], C, C, C);
-        copy(blob + S.r1_b, t[31], C);
+        fold_ln(t[30], t[31], t[28], t[29], C, C, Wf, bf);
+        pack_frags(blob + S.r1_w, Wf.data(), C, C, C);
+        copy(blob + S.r1_b, bf.data(), C);
         pack_frags(blob + S.r2_w, t[32], C, C, C);
         copy(blob + S.r2_b, t[33], C);
         copy(blob + S.se0_w, t[34], (size_t)(C / 4) * C);

@@ -108,6 +108,8 @@ def test_pack_weights_fragment_order(lib):
                        (f"down4.{rsh}.dense2.weight", None), ("down4.conv2.weight", None),
                        ("detector_head.dense.weight", 80)]:
         t = sd[name]
+        if name.endswith(f"{rsh}.dense1.weight"):      # LayerNorm gamma folded into the consuming Linear
+            t = t * sd[name.replace("dense1.weight", "norm.weight")][None, :]
         sub = t.numpy().ravel() if name == "down1.conv.0.weight" else frags(t, npad)
         o = find(sub)
         assert o >= 0 and o % 64 == 0, name
