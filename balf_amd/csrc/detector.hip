@@ -24,166 +24,10 @@
 //   se_kernel        per image: mean(t) -> C/4 -> C MLP -> sigmoid                (deterministic order)
 //   pool_kernel      stages 1-3: x2 = t*s + r, 2x2 max pool -> next stage's NHWC input
 //   head_kernel      stage 4: x2 -> conv2 -> relu -> dense(256->65) -> BN -> softmax -> pixel shuffle
-#include "common.h"
-#include "layout.h"
-#include "prof.h"
+#include "det_common.h"
 
+namespace balf {
 namespace {
-
-using namespace balf;
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ f4 ldg4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
-
-template <int C> struct StageP;               // pixel tiles (of 16) per wave
-template <> struct StageP<32> { static constexpr int P = 4; };
-template <> struct StageP<64> { static constexpr int P = 2; };
-template <> struct StageP<128> { static constexpr int P = 1; };
-template <> struct StageP<256> { static constexpr int P = 1; };
-
-constexpr int kBtPitch = kTokens + 4;          // floats per channel row of the transposed token tile
-
-// ------------------------------------------------------------------------------------------------
-// register-tile helpers: a [C]-channel activation of 16*P pixels is f4 t[NT][P], NT = C/16
-// ------------------------------------------------------------------------------------------------
-template <int NT, int P>
-__device__ __forceinline__ void init_bias(f4 (&t)[NT][P], const float *bias, int q) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const f4 b = ldg4(bias + 16 * nt + 4 * q);
-#pragma unroll
-        for (int p = 0; p < P; ++p) t[nt][p] = b;
-    }
-}
-
-// Exact (erf) GELU, nn.GELU() default (mlp_ma_decoder.py:52,99,126): x * Phi(x), with
-// Phi(-|x|) = 0.5 * erfc(|x| / sqrt 2) from Abramowitz-Stegun 7.1.26 (|erfc error| < 1.5e-7).  Measured
-// max-abs error of the whole expression vs fp64 over [-12, 12]: 4.2e-7 (torch's own fp32 GELU: 1.2e-6).
-// ~14 VALU instructions (one v_rcp_f32, one v_exp_f32) instead of ~35 for 0.5x(1 + erff(x/sqrt 2)).
-__device__ __forceinline__ float gelu1(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
-    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);     // coefficients pre-scaled by 1/2
-    p = fmaf(p, t, 0.5f * 1.421413741f);
-    p = fmaf(p, t, 0.5f * -0.284496736f);
-    p = fmaf(p, t, 0.5f * 0.254829592f);
-    const float y = p * t * e;                     // Phi(-|x|)
-    return fmaxf(x, 0.0f) - ax * y;                // x >= 0: x(1 - y);  x < 0: x y
-}
-
-template <int NT, int P>
-__device__ __forceinline__ void gelu(f4 (&t)[NT][P]) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[nt][p][r] = gelu1(t[nt][p][r]);
-}
-
-template <int NT, int P>
-__device__ __forceinline__ void relu(f4 (&t)[NT][P]) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[nt][p][r] = fmaxf(t[nt][p][r], 0.0f);
-}
-
-template <int NT, int P>
-__device__ __forceinline__ void lrelu(f4 (&t)[NT][P]) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = t[nt][p][r];
-                t[nt][p][r] = v > 0.0f ? v : 0.2f * v;
-            }
-}
-
-__device__ __forceinline__ float quarter_allreduce(float v) {   // the 4 lanes l, l^16, l^32, l^48
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
-// LayerNorm over the channel axis (eps 1e-5, affine), y may alias x.
-template <int NT, int P>
-__device__ __forceinline__ void layernorm(const f4 (&x)[NT][P], f4 (&y)[NT][P], const float *g, const float *b,
-                                          int q) {
-    constexpr float inv_c = 1.0f / (16 * NT);
-    float mean[P], rstd[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        float s = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) s += (x[nt][p][0] + x[nt][p][1]) + (x[nt][p][2] + x[nt][p][3]);
-        mean[p] = quarter_allreduce(s) * inv_c;
-        float v = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = x[nt][p][r] - mean[p];
-                v += d * d;
-            }
-        rstd[p] = 1.0f / sqrtf(quarter_allreduce(v) * inv_c + kLnEps);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const f4 gg = ldg4(g + 16 * nt + 4 * q), bb = ldg4(b + 16 * nt + 4 * q);
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[nt][p][r] = (x[nt][p][r] - mean[p]) * rstd[p] * gg[r] + bb[r];
-    }
-}
-
-// LayerNorm without the affine part: (x - mean) * rstd.  Used where gamma/beta were folded into the
-// weights/bias of the Linear that consumes the result (weights.hip: fold_ln).
-template <int NT, int P>
-__device__ __forceinline__ void layernorm_plain(const f4 (&x)[NT][P], f4 (&y)[NT][P]) {
-    constexpr float inv_c = 1.0f / (16 * NT);
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        float s = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) s += (x[nt][p][0] + x[nt][p][1]) + (x[nt][p][2] + x[nt][p][3]);
-        const float mean = quarter_allreduce(s) * inv_c;
-        float v = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = x[nt][p][r] - mean;
-                v = fmaf(d, d, v);
-            }
-        const float rstd = 1.0f / sqrtf(quarter_allreduce(v) * inv_c + kLnEps);
-        const float shift = -mean * rstd;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[nt][p][r] = fmaf(x[nt][p][r], rstd, shift);
-    }
-}
-
-template <int NT, int P>
-__device__ __forceinline__ void store_slot(f4 *slot, const f4 (&t)[NT][P], int lane) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int p = 0; p < P; ++p) slot[(nt * P + p) * 64 + lane] = t[nt][p];
-}
-
 // ------------------------------------------------------------------------------------------------
 // GEMM: acc[NT0 .. NT0+NTC)[P] += W[rows of weight tiles wnt0.. , K range kt0..kt0+ktn) * in
 //   wf    : fragment-ordered weights (layout.h), KTtot = K/16 tiles per weight row-tile
@@ -250,25 +94,6 @@ __device__ __forceinline__ void gemm(f4 (&acc)[NTT][P], const float *w, int wnt0
                                      int lane, BL bload) {
     constexpr int CH = (P >= 4) ? 2 : ((P == 2 || NTT <= 16) ? 4 : 8);
     gemm_from<NTT, 0, CH, P>(acc, reinterpret_cast<const f4 *>(w), wnt0, KTtot, kt0, ktn, lane, bload);
-}
-
-// ------------------------------------------------------------------------------------------------
-struct StageArgs {
-    const float *blob;
-    StageOff off;
-    const float *X;       // stage input: NCHW [B,3,H,W] (stage 1) or NHWC [B,H,W,CIN]
-    int B, H, W;          // resolution of this stage
-    float *U;             // [B,H,W,C] grid-branch output u'
-    float *T;             // [B,H,W,C] RCAB body output t
-    float *R;             // [B,H,W,C] x1 + x0
-    float *partial;       // [B, wgs_per_image, C] channel sums of t
-};
-
-template <int C, int P>
-constexpr int stage_lds_bytes() {
-    constexpr int slots = 4 * (C / 16) * P * 1024;
-    constexpr int bt = P * C * kBtPitch * 4;
-    return (slots > bt ? slots : bt) + 4 * C * 4;
 }
 
 template <int C, int CIN, int MODE>
@@ -465,60 +290,6 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel(S
 }
 
 // ------------------------------------------------------------------------------------------------
-// squeeze-excite: s[n, :] = sigmoid(W2 relu(W0 mean_hw(t) + b0) + b2)   (mlp_ma_decoder.py:166-171)
-// ------------------------------------------------------------------------------------------------
-// Level 1: [B, per_img, C] workgroup sums -> [B, kSeChunks, C] chunk sums (fixed order: deterministic).
-constexpr int kSeChunks = 64;
-
-template <int C>
-__global__ __launch_bounds__(256) void se_reduce_kernel(const float *__restrict__ partial, int per_img,
-                                                        float *__restrict__ chunk) {
-    constexpr int PARTS = 256 / C > 0 ? 256 / C : 1;
-    __shared__ float s_part[PARTS][C];
-    const int n = blockIdx.x / kSeChunks, ch = blockIdx.x % kSeChunks;
-    const int per_chunk = (per_img + kSeChunks - 1) / kSeChunks;
-    const int i0 = ch * per_chunk, i1 = (i0 + per_chunk < per_img) ? i0 + per_chunk : per_img;
-    const float *pp = partial + (long)n * per_img * C;
-    {
-        const int c = threadIdx.x % C, part = threadIdx.x / C;       // 256 threads = PARTS x C exactly
-        float acc = 0.0f;
-        for (int i = i0 + part; i < i1; i += PARTS) acc += pp[(long)i * C + c];
-        s_part[part][c] = acc;
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc = 0.0f;
-        for (int k = 0; k < PARTS; ++k) acc += s_part[k][c];
-        chunk[((long)n * kSeChunks + ch) * C + c] = acc;
-    }
-}
-
-template <int C>
-__global__ __launch_bounds__(256) void se_kernel(const float *blob, StageOff S, const float *chunk, float inv_hw,
-                                                 float *scale) {
-    __shared__ float s_mean[C];
-    __shared__ float s_hid[C / 4];
-    const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc = 0.0f;
-        for (int k = 0; k < kSeChunks; ++k) acc += chunk[((long)n * kSeChunks + k) * C + c];
-        s_mean[c] = acc * inv_hw;
-    }
-    __syncthreads();
-    for (int h = threadIdx.x; h < C / 4; h += 256) {
-        float acc = blob[S.se0_b + h];
-        for (int c = 0; c < C; ++c) acc += blob[S.se0_w + h * C + c] * s_mean[c];
-        s_hid[h] = fmaxf(acc, 0.0f);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc = blob[S.se2_b + c];
-        for (int h = 0; h < C / 4; ++h) acc += blob[S.se2_w + c * (C / 4) + h] * s_hid[h];
-        scale[(long)n * C + c] = 1.0f / (1.0f + expf(-acc));
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // x2 = t * s + r, MaxPool2d(2) -> next stage input, NHWC                 (mlp_ma_decoder.py:232-236)
 // ------------------------------------------------------------------------------------------------
 template <int C>
@@ -551,19 +322,6 @@ __global__ __launch_bounds__(256) void pool_kernel(const float *__restrict__ T, 
         *reinterpret_cast<f4 *>(out + i * 4) = m;
     }
 }
-
-// ------------------------------------------------------------------------------------------------
-// stage-4 tail + detector head: one wave = 16 pixels of the 1/8-resolution map
-// ------------------------------------------------------------------------------------------------
-struct HeadArgs {
-    const float *blob;
-    StageOff off;            // stage 4 (conv2)
-    int head_w, head_b, head_alpha, head_beta;
-    const float *T, *R, *scale;   // [B,h,w,256], [B,256]
-    int B, h, w;             // 1/8 resolution
-    float *logits;           // [B,65,h,w] or nullptr
-    float *prob;             // [B,8h,8w]
-};
 
 __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
     constexpr int C = 256, NT = 16, HT = kHeadNPad / 16;
@@ -626,37 +384,6 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------------
-struct Plan {
-    int mb;                 // images per micro-batch
-    size_t off_U, off_T, off_R, off_X[3], off_partial, off_chunk, off_scale, total;
-};
-
-Plan make_plan(int B, int Hp, int Wp) {
-    Plan p{};
-    const long px = (long)Hp * Wp;
-    long mb = (16L * 1024 * 1024) / px;                // <= 16.8 Mpx of stage-1 activations in flight
-    if (mb < 1) mb = 1;
-    if (mb > B) mb = B;
-    p.mb = (int)mb;
-    size_t o = 0;
-    auto take = [&](size_t floats) { size_t r = o; o = balf_align_up(o + floats * sizeof(float), 256); return r; };
-    const size_t big = (size_t)mb * px * 32;           // every stage: H*W*C = px * 32 / 2^(s)
-    p.off_U = take(big);
-    p.off_T = take(big);
-    p.off_R = take(big);
-    p.off_X[0] = take((size_t)mb * (px / 4) * 32);
-    p.off_X[1] = take((size_t)mb * (px / 16) * 64);
-    p.off_X[2] = take((size_t)mb * (px / 64) * 128);
-    p.off_partial = take((size_t)mb * (px / 64) * 32);  // groups/P * C <= px/64 * 32 for every stage
-    p.off_chunk = take((size_t)mb * kSeChunks * 256);
-    p.off_scale = take((size_t)mb * 256);
-    p.total = o;
-    return p;
-}
-
 template <int C, int CIN>
 int run_stage(const float *blob, int s, const float *X, int B, int H, int W, float *U, float *T, float *R,
               float *partial, float *chunk, float *scale, hipStream_t st) {
@@ -699,24 +426,8 @@ int run_pool(int s, const float *T, const float *R, const float *scale, int B, i
 
 }  // namespace
 
-extern "C" size_t balf_forward_workspace_bytes(int B, int Hp, int Wp) {
-    if (B <= 0 || Hp <= 0 || Wp <= 0 || Hp % 64 || Wp % 64) return 0;
-    return make_plan(B, Hp, Wp).total;
-}
-
-extern "C" int balf_forward(const void *packed_dev, int precision, const float *x_nchw_dev, int B, int Hp, int Wp,
-                            float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
-                            void *stream) {
-    if (!packed_dev || !x_nchw_dev || !prob_dev || !workspace_dev) return BALF_ERR_ARG;
-    if (precision != BALF_PREC_FP32) return BALF_ERR_ARG;
-    if (B <= 0 || Hp <= 0 || Wp <= 0) return BALF_ERR_ARG;
-    if (Hp % 64 || Wp % 64) return BALF_ERR_SHAPE;
-    if ((long)B * Hp * Wp * 32 > 0x7fffffffffL) return BALF_ERR_SHAPE;
-    const Plan pl = make_plan(B, Hp, Wp);
-    if (workspace_bytes < pl.total) return BALF_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    const float *blob = static_cast<const float *>(packed_dev);
-    char *ws = static_cast<char *>(workspace_dev);
+int forward_f32(const float *blob, const float *x_nchw_dev, int B, int Hp, int Wp, float *logits_dev, float *prob_dev,
+                char *ws, const Plan &pl, hipStream_t st) {
     float *U = reinterpret_cast<float *>(ws + pl.off_U), *T = reinterpret_cast<float *>(ws + pl.off_T),
           *R = reinterpret_cast<float *>(ws + pl.off_R), *partial = reinterpret_cast<float *>(ws + pl.off_partial),
           *chunk = reinterpret_cast<float *>(ws + pl.off_chunk), *scale = reinterpret_cast<float *>(ws + pl.off_scale);
@@ -744,4 +455,28 @@ extern "C" int balf_forward(const void *packed_dev, int precision, const float *
         BALF_LAUNCH_CHECK();
     }
     return BALF_OK;
+}
+
+}  // namespace balf
+
+extern "C" size_t balf_forward_workspace_bytes(int B, int Hp, int Wp) {
+    if (B <= 0 || Hp <= 0 || Wp <= 0 || Hp % 64 || Wp % 64) return 0;
+    return balf::make_plan(B, Hp, Wp).total;
+}
+
+extern "C" int balf_forward(const void *packed_dev, int precision, const float *x_nchw_dev, int B, int Hp, int Wp,
+                            float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
+                            void *stream) {
+    if (!packed_dev || !x_nchw_dev || !prob_dev || !workspace_dev) return BALF_ERR_ARG;
+    if (precision != BALF_PREC_FP32 && precision != BALF_PREC_FP16) return BALF_ERR_ARG;
+    if (B <= 0 || Hp <= 0 || Wp <= 0) return BALF_ERR_ARG;
+    if (Hp % 64 || Wp % 64) return BALF_ERR_SHAPE;
+    if ((long)B * Hp * Wp * 32 > 0x7fffffffffL) return BALF_ERR_SHAPE;
+    const balf::Plan pl = balf::make_plan(B, Hp, Wp);
+    if (workspace_bytes < pl.total) return BALF_ERR_WORKSPACE;
+    const float *blob = static_cast<const float *>(packed_dev);
+    char *ws = static_cast<char *>(workspace_dev);
+    return precision == BALF_PREC_FP32
+               ? balf::forward_f32(blob, x_nchw_dev, B, Hp, Wp, logits_dev, prob_dev, ws, pl, (hipStream_t)stream)
+               : balf::forward_f16(blob, x_nchw_dev, B, Hp, Wp, logits_dev, prob_dev, ws, pl, (hipStream_t)stream);
 }

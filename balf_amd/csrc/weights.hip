@@ -83,6 +83,29 @@ void pack_frags(float *dst, const float *W, int N, int K, int Npad) {
 
 void copy(float *dst, const float *src, size_t n) { memcpy(dst, src, n * sizeof(float)); }
 
+// Split-f16 fragments for v_mfma_f32_16x16x32_f16 (detector_f16.hip).  Weight tile (nt, ks) occupies 2 KiB:
+// [hi: 64 lanes x 8 halves][lo: 64 lanes x 8 halves], hi = f16(w) (round to nearest even), lo = f16(w - hi).
+// `permuted` = the K order of the register chain: k-slot (q, j) of K-step ks holds input channel
+// 32 ks + 16 (j >> 2) + 4 q + (j & 3); natural order (k = 32 ks + 8 q + j) is used for the token-mix matrix,
+// whose K axis is the token index read linearly from LDS.  The region has the same size as the fp32 one.
+void pack_frags16(float *dst_region, const float *W, int N, int K, int Npad, bool permuted) {
+    _Float16 *dst = reinterpret_cast<_Float16 *>(dst_region);
+    const int KS = K / 32;
+    for (int nt = 0; nt < Npad / 16; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 16 * nt + (lane & 15), q = lane >> 4;
+                    const int k = permuted ? 32 * ks + 16 * (j >> 2) + 4 * q + (j & 3) : 32 * ks + 8 * q + j;
+                    const float w = n < N ? W[(size_t)n * K + k] : 0.0f;
+                    const _Float16 hi = (_Float16)w;
+                    const _Float16 lo = (_Float16)(w - (float)hi);
+                    const size_t tile = ((size_t)nt * KS + ks) * 1024;          // halves per 2 KiB tile
+                    dst[tile + lane * 8 + j] = hi;
+                    dst[tile + 512 + lane * 8 + j] = lo;
+                }
+}
+
 // LayerNorm(x; gamma, beta) followed by Linear(W, b):  W (n * gamma + beta) + b = (W diag gamma) n + (W beta + b)
 // where n = (x - mean) * rstd.  Folding the affine part into the Linear removes 3 VALU ops per element
 // from the kernels (the f32 MFMA shares its pipe with the VALU, so they are not free).
@@ -115,33 +138,39 @@ extern "C" size_t balf_state_tensor_numel(int i) {
 }
 
 extern "C" size_t balf_packed_weights_bytes(int precision) {
-    if (precision != BALF_PREC_FP32) return 0;
-    return (size_t)kLayout.total * sizeof(float);
+    if (precision != BALF_PREC_FP32 && precision != BALF_PREC_FP16) return 0;
+    return (size_t)kLayout.total * sizeof(float);       // both blobs share layout.h's offsets
 }
 
 extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int precision, void *packed_host,
                                  size_t packed_bytes) {
     if (!tensors || !packed_host) return BALF_ERR_ARG;
     if (n_tensors != kNumStateTensors || (int)table().size() != kNumStateTensors) return BALF_ERR_ARG;
-    if (precision != BALF_PREC_FP32) return BALF_ERR_ARG;
+    if (precision != BALF_PREC_FP32 && precision != BALF_PREC_FP16) return BALF_ERR_ARG;
     if (packed_bytes < balf_packed_weights_bytes(precision)) return BALF_ERR_WORKSPACE;
     for (int i = 0; i < n_tensors; ++i)
         if (!tensors[i]) return BALF_ERR_ARG;
 
     float *blob = static_cast<float *>(packed_host);
     memset(blob, 0, (size_t)kLayout.total * sizeof(float));
+    const bool f16 = precision == BALF_PREC_FP16;
+    // MFMA-operand weights: fp32 A fragments, or split-f16 fragments in the same region
+    auto pack = [&](float *dst, const float *W, int N, int K, int Npad) {
+        if (f16) pack_frags16(dst, W, N, K, Npad, true);
+        else pack_frags(dst, W, N, K, Npad);
+    };
     for (int s = 0; s < kStages; ++s) {
         const int C = kC[s], Cin = kCin[s];
         const StageOff &S = kLayout.st[s];
         const float *const *t = tensors + s * kTensorsPerStage;
         if (s == 0) copy(blob + S.conv0_w, t[0], (size_t)C * Cin);
-        else pack_frags(blob + S.conv0_w, t[0], C, Cin, C);
+        else pack(blob + S.conv0_w, t[0], C, Cin, C);
         copy(blob + S.conv0_b, t[1], C);
         std::vector<float> Wf, bf;
         copy(blob + S.qln_g, t[2], C);                 // kept for reference; the kernels use the folded form
         copy(blob + S.qln_b, t[3], C);
         fold_ln(t[4], t[5], t[2], t[3], 2 * C, C, Wf, bf);
-        pack_frags(blob + S.q1_w, Wf.data(), 2 * C, C, 2 * C);
+        pack(blob + S.q1_w, Wf.data(), 2 * C, C, 2 * C);
         copy(blob + S.q1_b, bf.data(), 2 * C);
         for (int b = 0; b < 2; ++b) {
             const BranchOff &B = S.br[b];
@@ -149,33 +178,34 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
             copy(blob + B.ln_g, u[0], C);
             copy(blob + B.ln_b, u[1], C);
             fold_ln(u[2], u[3], u[0], u[1], 2 * C, C, Wf, bf);
-            pack_frags(blob + B.d1_w, Wf.data(), 2 * C, C, 2 * C);
+            pack(blob + B.d1_w, Wf.data(), 2 * C, C, 2 * C);
             copy(blob + B.d1_b, bf.data(), 2 * C);
             copy(blob + B.gln_g, u[4], C);
             copy(blob + B.gln_b, u[5], C);
-            pack_frags(blob + B.mix_w, u[6], kTokens, kTokens, kTokens);
+            if (f16) pack_frags16(blob + B.mix_w, u[6], kTokens, kTokens, kTokens, false);
+            else pack_frags(blob + B.mix_w, u[6], kTokens, kTokens, kTokens);
             copy(blob + B.mix_b, u[7], kTokens);
-            pack_frags(blob + B.d2_w, u[8], C, C, C);
+            pack(blob + B.d2_w, u[8], C, C, C);
             copy(blob + B.d2_b, u[9], C);
         }
-        pack_frags(blob + S.q2_w, t[26], C, 2 * C, C);
+        pack(blob + S.q2_w, t[26], C, 2 * C, C);
         copy(blob + S.q2_b, t[27], C);
         copy(blob + S.rln_g, t[28], C);
         copy(blob + S.rln_b, t[29], C);
         fold_ln(t[30], t[31], t[28], t[29], C, C, Wf, bf);
-        pack_frags(blob + S.r1_w, Wf.data(), C, C, C);
+        pack(blob + S.r1_w, Wf.data(), C, C, C);
         copy(blob + S.r1_b, bf.data(), C);
-        pack_frags(blob + S.r2_w, t[32], C, C, C);
+        pack(blob + S.r2_w, t[32], C, C, C);
         copy(blob + S.r2_b, t[33], C);
         copy(blob + S.se0_w, t[34], (size_t)(C / 4) * C);
         copy(blob + S.se0_b, t[35], C / 4);
         copy(blob + S.se2_w, t[36], (size_t)C * (C / 4));
         copy(blob + S.se2_b, t[37], C);
-        pack_frags(blob + S.conv2_w, t[38], C, C, C);
+        pack(blob + S.conv2_w, t[38], C, C, C);
         copy(blob + S.conv2_b, t[39], C);
     }
     const float *const *h = tensors + kStages * kTensorsPerStage;
-    pack_frags(blob + kLayout.head_w, h[0], kHeadN, kC[3], kHeadNPad);
+    pack(blob + kLayout.head_w, h[0], kHeadN, kC[3], kHeadNPad);
     copy(blob + kLayout.head_b, h[1], kHeadN);
     for (int c = 0; c < kHeadN; ++c) {
         // BatchNorm2d in eval mode (/root/reference/balf/model/decoder.py:12,22):

@@ -28,6 +28,55 @@ def model():
     return m.eval().to("cuda:0")
 
 
+@pytest.fixture(scope="module")
+def model16():
+    """The f16-MFMA path with split (hi+lo) operands: same tolerance as the fp32 path's north-star bar."""
+    from balf_amd.model import get_model
+    m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m.load_state_dict(synth.synthetic_state_dict(cases.WEIGHT_SEED))
+    m.precision = "fp16"
+    return m.eval().to("cuda:0")
+
+
+@pytest.mark.parametrize("name", list(cases.FORWARD_SMALL))
+def test_f16_split_forward_vs_reference_golden(model16, name):
+    f = np.load(os.path.join(G, "forward_small.npz"))
+    b, h, w, seed = cases.FORWARD_SMALL[name]
+    with torch.inference_mode():
+        out = model16(cases.forward_input(b, h, w, seed).to("cuda:0"))
+    perr = np.abs(out["prob"].cpu().numpy() - f[name + ".prob"]).max()
+    lerr = np.abs(out["logits"].cpu().numpy() - f[name + ".logits"]).max()
+    print(name, "f16x3 prob err", perr, "logit err", lerr)
+    assert perr < PROB_TOL and lerr < LOGIT_TOL
+
+
+def test_f16_split_vga_detections(model16):
+    from balf_amd import ops
+    f = np.load(os.path.join(G, "forward_cfg.npz"))
+    h, w, k, img_index = cases.FORWARD_CFG["vga"]
+    img = synth.gray_to_rgb_norm(synth.synthetic_gray_u8(h, w, img_index))
+    pad = O.mod_padding_symmetric(O.make_shape_even(img), 64)
+    x = torch.tensor(pad, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0).to("cuda:0")
+    with torch.inference_mode():
+        prob = model16(x)["prob"]
+    p = prob[0].cpu().numpy()
+    assert np.abs(p[::8, ::8] - f["vga.prob_s8"]).max() < PROB_TOL
+    top, left = O.crop_offsets(h, w, *p.shape)
+    idx, sc, cnt = ops.nms_topk(prob, top, left, h, w, 15, 15, k)
+    overlap = np.intersect1d(idx[0].cpu().numpy(), f["vga.idx"]).size / k
+    print("f16x3 end-to-end index overlap with the reference:", overlap)
+    assert overlap > 0.97
+
+
+def test_f16_split_determinism_and_batch_invariance(model16):
+    x = cases.forward_input(3, 128, 192, 99).to("cuda:0")
+    with torch.inference_mode():
+        a = model16(x)["prob"]
+        b = model16(x)["prob"]
+        c = torch.cat([model16(x[i:i + 1])["prob"] for i in range(3)])
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
 @pytest.mark.parametrize("name", list(cases.FORWARD_SMALL))
 def test_forward_small_vs_reference_golden(model, name):
     f = np.load(os.path.join(G, "forward_small.npz"))

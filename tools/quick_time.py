@@ -8,6 +8,7 @@ from balf_amd.utils import synth
 
 m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
 m.load_state_dict(synth.synthetic_state_dict(1))
+m.precision = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 m = m.eval().cuda()
 for (b, h, w, k) in [(32, 512, 640, 1000), (8, 1088, 1920, 2000), (32, 1088, 1920, 2000)]:
     x = torch.rand((b, 3, h, w), device="cuda")
