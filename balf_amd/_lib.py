@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbalf_hip.so")
+LIB_PATH = os.environ.get("BALF_HIP_LIB", os.path.join(_HERE, "libbalf_hip.so"))   # override: tuning builds only
 
 OK = 0
 PREC_FP32, PREC_FP16 = 0, 1

@@ -16,11 +16,27 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
 
 __device__ __forceinline__ f4 ldg4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 
+// Tuning: pixel tiles (of 16) per wave and the register-allocation target (waves per SIMD) per stage.
+#ifndef BALF_P32
+#define BALF_P32 4
+#endif
+#ifndef BALF_P64
+#define BALF_P64 2
+#endif
+#ifndef BALF_OCC32
+#define BALF_OCC32 2
+#endif
+#ifndef BALF_OCC64
+#define BALF_OCC64 2
+#endif
+#ifndef BALF_OCC128
+#define BALF_OCC128 2
+#endif
 template <int C> struct StageP;               // pixel tiles (of 16) per wave
-template <> struct StageP<32> { static constexpr int P = 4; };
-template <> struct StageP<64> { static constexpr int P = 2; };
-template <> struct StageP<128> { static constexpr int P = 1; };
-template <> struct StageP<256> { static constexpr int P = 1; };
+template <> struct StageP<32> { static constexpr int P = BALF_P32, OCC = BALF_OCC32; };
+template <> struct StageP<64> { static constexpr int P = BALF_P64, OCC = BALF_OCC64; };
+template <> struct StageP<128> { static constexpr int P = 1, OCC = BALF_OCC128; };
+template <> struct StageP<256> { static constexpr int P = 1, OCC = 1; };
 
 constexpr int kBtPitch = kTokens + 4;          // floats per channel row of the transposed token tile
 
@@ -50,7 +66,7 @@ __device__ __forceinline__ float gelu1(float x) {
     p = fmaf(p, t, 0.5f * -0.284496736f);
     p = fmaf(p, t, 0.5f * 0.254829592f);
     const float y = p * t * e;                     // Phi(-|x|)
-    return fmaxf(x, 0.0f) - ax * y;                // x >= 0: x(1 - y);  x < 0: x y
+    return fmaf(ax, 0.5f - y, 0.5f * x);           // = max(x, 0) - |x| y:  x >= 0: x(1 - y);  x < 0: x y
 }
 
 template <int NT, int P>
@@ -112,7 +128,7 @@ __device__ __forceinline__ void layernorm(const f4 (&x)[NT][P], f4 (&y)[NT][P], 
                 const float d = x[nt][p][r] - mean[p];
                 v += d * d;
             }
-        rstd[p] = 1.0f / sqrtf(quarter_allreduce(v) * inv_c + kLnEps);
+        rstd[p] = __builtin_amdgcn_rsqf(quarter_allreduce(v) * inv_c + kLnEps);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -143,7 +159,7 @@ __device__ __forceinline__ void layernorm_plain(const f4 (&x)[NT][P], f4 (&y)[NT
                 const float d = x[nt][p][r] - mean;
                 v = fmaf(d, d, v);
             }
-        const float rstd = 1.0f / sqrtf(quarter_allreduce(v) * inv_c + kLnEps);
+        const float rstd = __builtin_amdgcn_rsqf(quarter_allreduce(v) * inv_c + kLnEps);
         const float shift = -mean * rstd;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)

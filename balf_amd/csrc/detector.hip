@@ -97,7 +97,7 @@ __device__ __forceinline__ void gemm(f4 (&acc)[NTT][P], const float *w, int wnt0
 }
 
 template <int C, int CIN, int MODE>
-__global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel(StageArgs A) {
+__global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(StageArgs A) {
     constexpr int P = StageP<C>::P;
     constexpr int NT = C / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

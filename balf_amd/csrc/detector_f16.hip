@@ -21,6 +21,8 @@
 // Activations that are consumed as B operands straight from HBM (stage inputs X2..X4 and the grid-branch
 // output U) are stored pre-split in "fragment format": per pixel, per K-step 128 B = [hi: q0..q3 x 8
 // halves][lo: q0..q3 x 8 halves] -- the same bytes per pixel as fp32 NHWC.
+#include <type_traits>
+
 #include "det_common.h"
 
 namespace balf {
@@ -160,36 +162,225 @@ __device__ __forceinline__ void gemm16_from(f4 (&acc)[NTT][P], const float *w, i
     }
 }
 
+#ifndef BALF_ALIGN_WAVES
+#define BALF_ALIGN_WAVES 0
+#endif
 template <int NTT, int P, typename BL>
 __device__ __forceinline__ void gemm16(f4 (&acc)[NTT][P], const float *w, int wnt0, int KStot, int ks0, int ksn,
                                        int lane, BL bload) {
     constexpr int CH = (P >= 4) ? 2 : 4;
+    if (BALF_ALIGN_WAVES && P < 4) __builtin_amdgcn_s_barrier();   // keep the 4 waves on the same weight lines
     gemm16_from<NTT, 0, CH, P>(acc, w, wnt0, KStot, ks0, ksn, lane, bload);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Cooperative GEMM for C >= 64: weights go HBM/L2 -> LDS ring by LDS-DMA (global_load_lds, no VGPRs), each
+// 2 KiB weight tile is fetched ONCE per workgroup and read by all four waves from LDS.  Without it every
+// wave streams the whole weight matrix through the CU's 64 B/clk vector-memory path (~170/P B/clk of
+// demand when MFMA-bound), which is what bounds the per-wave version at C >= 64.
+//   unit u = (chunk c of 4 weight row-tiles, K-step k): 8 KiB = one ring slot; wave w DMA-loads tile w
+//   (hi + lo = 2 x 1 KiB wave-instructions).  Ring of 4 slots, 2 units in flight beyond the one in use:
+//   iteration u:  wait own loads of unit u (counted vmcnt)  ->  s_barrier (everyone's unit-u loads have
+//   landed; everyone is done reading slot (u-1)%4)  ->  DMA unit u+3 into slot (u-1)%4  ->  ds_read + MFMA.
+// ------------------------------------------------------------------------------------------------
+#ifndef BALF_RING_STRICT
+#define BALF_RING_STRICT 0
+#endif
+constexpr int kRingSlots = 4;
+constexpr int kRingNTC = 4;
+constexpr int kRingSlotBytes = kRingNTC * 2048;
+constexpr int kRingBytes = kRingSlots * kRingSlotBytes;
+
+struct RingGemm {
+    const char *wbase;     // first weight tile of the matrix (bytes)
+    int wnt0, KStot, ks0, ksn;
+    int chunks;            // groups of 4 weight row-tiles (units = chunks * ksn)
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+__device__ __forceinline__ void ring_issue(const RingGemm &g, unsigned char *ring, int u, int wave, int lane) {
+    const int c = u / g.ksn, k = u - c * g.ksn;
+    const char *src = g.wbase + ((size_t)(g.wnt0 + c * kRingNTC + wave) * g.KStot + g.ks0 + k) * 2048 + lane * 16;
+    unsigned char *dst = ring + (u & (kRingSlots - 1)) * kRingSlotBytes + wave * 2048;   // wave-uniform
+    __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void *)(src + 1024), (lds_void *)(dst + 1024), 16, 0, 0);
+}
+
+// The ring is CHAINED across the consecutive Linears of a kernel: units are numbered globally over the whole
+// sequence of GEMMs, and iteration G always issues global unit G + 3, which may belong to one of the next
+// GEMMs -- so the first tiles of the next Linear arrive while the current epilogue (GELU, LayerNorm, ...)
+// runs, and short GEMMs (2 units at C = 64) do not pay a pipeline refill each.
+struct RingChain {         // by value, indexed with compile-time constants only: stays in SGPRs
+    RingGemm g[4];          // current GEMM and up to three successors
+    int tot[4];             // units of each (0 = absent)
+};
+
+template <int NTT>
+__device__ __forceinline__ RingChain make_chain(const RingGemm &g0, const RingGemm &g1, const RingGemm &g2,
+                                                const RingGemm &g3, int n) {
+    RingChain c;
+    c.g[0] = g0; c.g[1] = g1; c.g[2] = g2; c.g[3] = g3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.tot[i] = (i < n) ? c.g[i].chunks * c.g[i].ksn : 0;
+    return c;
+}
+
+// issue chain-relative unit t (t >= 0 counted from unit 0 of chain.g[0]) into ring slot `slot`
+__device__ __forceinline__ void chain_issue(const RingChain &c, unsigned char *ring, int t, int slot, int wave,
+                                            int lane) {
+    RingGemm d = c.g[0];
+    bool valid = c.tot[0] > 0, walking = true;        // step through the chain until t falls inside a GEMM
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (walking) {
+            if (valid && t >= c.tot[i]) {
+                t -= c.tot[i];
+                if (i < 3) { d = c.g[i + 1]; valid = c.tot[i + 1] > 0; }
+                else valid = false;
+            } else {
+                walking = false;
+            }
+        }
+    if (!valid) return;
+    const int cc = t / d.ksn, k = t - cc * d.ksn;
+    const char *src = d.wbase + ((size_t)(d.wnt0 + cc * kRingNTC + wave) * d.KStot + d.ks0 + k) * 2048 + lane * 16;
+    unsigned char *dst = ring + slot * kRingSlotBytes + wave * 2048;                    // wave-uniform
+    __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void *)(src + 1024), (lds_void *)(dst + 1024), 16, 0, 0);
+}
+
+template <int NTT, int CI, int P, typename BL>
+__device__ __forceinline__ void chain_chunk(f4 (&acc)[NTT][P], const RingChain &c, unsigned char *ring, int gu,
+                                            int lane, int wave, BL bload) {
+    if constexpr (CI * kRingNTC < NTT) {
+        const int ksn = c.g[0].ksn;
+        const int later = c.tot[1] + c.tot[2] + c.tot[3];
+        for (int k = 0; k < ksn; ++k) {
+            const int u = CI * ksn + k;
+            const int after = c.tot[0] - 1 - u + later;      // units issued after u, capped at slots - 2
+            // wait + barrier as ONE asm statement with a memory clobber: the raw s_barrier builtin is
+            // IntrNoMem, i.e. the compiler may otherwise hoist the ring's ds_reads above it.  lgkmcnt(0)
+            // retires this wave's ds_reads of slot (u-1)%4 BEFORE the barrier: hipcc sinks the MFMAs that
+            // consume them (and their lgkmcnt wait) below the barrier, and the slot is re-filled by DMA right
+            // after it -- without this, two workgroups per CU produced wrong tiles under load (WAR race)
+            if (BALF_RING_STRICT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (after >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (after == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            chain_issue(c, ring, u + kRingSlots - 1, (gu + u + kRingSlots - 1) & (kRingSlots - 1), wave, lane);
+            const unsigned char *slot = ring + ((gu + u) & (kRingSlots - 1)) * kRingSlotBytes + lane * 16;
+            HL a[kRingNTC], b[P];
+#pragma unroll
+            for (int nt = 0; nt < kRingNTC; ++nt) {
+                a[nt].hi = *reinterpret_cast<const h8 *>(slot + nt * 2048);
+                a[nt].lo = *reinterpret_cast<const h8 *>(slot + nt * 2048 + 1024);
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) b[p] = bload(k, p);
+#pragma unroll
+            for (int nt = 0; nt < kRingNTC; ++nt)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[CI * kRingNTC + nt][p] = mfma16(a[nt].lo, b[p].hi, acc[CI * kRingNTC + nt][p]);
+#pragma unroll
+            for (int nt = 0; nt < kRingNTC; ++nt)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[CI * kRingNTC + nt][p] = mfma16(a[nt].hi, b[p].lo, acc[CI * kRingNTC + nt][p]);
+#pragma unroll
+            for (int nt = 0; nt < kRingNTC; ++nt)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[CI * kRingNTC + nt][p] = mfma16(a[nt].hi, b[p].hi, acc[CI * kRingNTC + nt][p]);
+        }
+        chain_chunk<NTT, CI + 1, P>(acc, c, ring, gu, lane, wave, bload);
+    }
+}
+
+// Run chain.g[0].  `gu` = global index of its unit 0 (advanced by the caller); `first` = nothing has been
+// issued yet (first GEMM of the kernel): prime global units 0..2.  All four waves call this together.
+template <int NTT, int P, typename BL>
+__device__ __forceinline__ void gemm16_chain(f4 (&acc)[NTT][P], const RingChain &c, int &gu, bool first, int lane,
+                                             int wave, unsigned char *ring, BL bload) {
+    static_assert(NTT % kRingNTC == 0, "row tiles must come in groups of 4");
+    if (first)
+        for (int t = 0; t < kRingSlots - 1; ++t) chain_issue(c, ring, t, (gu + t) & (kRingSlots - 1), wave, lane);
+    chain_chunk<NTT, 0, P>(acc, c, ring, gu, lane, wave, bload);
+    gu += c.tot[0];
+}
+
+// workgroup barrier that orders LDS traffic only: no vmcnt(0), so LDS-DMA prefetches stay in flight
+#ifndef BALF_RAW_LDS_BARRIER
+#define BALF_RAW_LDS_BARRIER 1
+#endif
+#ifndef BALF_MIX_RING
+#define BALF_MIX_RING 1
+#endif
+__device__ __forceinline__ void lds_barrier() {
+    if (BALF_RAW_LDS_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
+
 constexpr int kBtPitch16 = kTokens + 8;        // halves per channel row of the transposed token tile
+
+#ifndef BALF_COOP_MIN_C
+#define BALF_COOP_MIN_C 64
+#endif
+template <int C>
+constexpr bool use_ring() { return C >= BALF_COOP_MIN_C; }
+
+// Per-channel parameters of a stage kernel cached in LDS (so that no ordinary VMEM load sits between the
+// chained LDS-DMA prefetches and their consumers: vmcnt completes in order).  Offsets in floats:
+template <int C> constexpr int par_floats() { return 10 * C + 64; }
+enum ParOff { kParConv0B = 0, kParQ1B = 1, kParD1B = 2, kParGlnG = 4, kParGlnB = 5, kParD2B = 6, kParMixB = 7,
+              kParQ2B = 7, kParR1B = 8, kParR2B = 9 };      // x C  (kParQ2B.. are + 64 past kParMixB)
 
 template <int C, int P>
 constexpr int stage_lds_bytes16() {
     constexpr int slots = 4 * (C / 32) * P * 2048;
     constexpr int bt = 2 * P * C * kBtPitch16 * 2;
-    return (slots > bt ? slots : bt) + 4 * C * 4;
+    return (slots > bt ? slots : bt) + 4 * C * 4 + (use_ring<C>() ? kRingBytes : 0) + par_floats<C>() * 4;
 }
 
 template <int C, int CIN, int MODE>
-__global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel16(StageArgs A) {
+__global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(StageArgs A) {
     constexpr int P = StageP<C>::P;
     constexpr int NT = C / 16, KS = C / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int main_bytes = stage_lds_bytes16<C, P>() - 4 * C * 4;
+    constexpr int main_bytes =
+        stage_lds_bytes16<C, P>() - 4 * C * 4 - (use_ring<C>() ? kRingBytes : 0) - par_floats<C>() * 4;
     _Float16 *bT = reinterpret_cast<_Float16 *>(smem_raw);                 // [hi|lo][p][c][pitch]
     float *red = reinterpret_cast<float *>(smem_raw + main_bytes);         // [4][C]
+    unsigned char *ring = smem_raw + main_bytes + 4 * C * 4;               // weight ring (C >= 64)
+    float *par = reinterpret_cast<float *>(smem_raw + main_bytes + 4 * C * 4 + (use_ring<C>() ? kRingBytes : 0));
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, li = lane & 15;
     h8 *slot = reinterpret_cast<h8 *>(smem_raw) + wave * (KS * P * 2 * 64);
     const float *blob = A.blob;
     const StageOff &S = A.off;
     const BranchOff &Br = S.br[MODE];
+
+    {   // parameter cache (see par_floats)
+        auto put = [&](int dst, int src, int n) {
+            for (int i = threadIdx.x; i < n; i += 256) par[dst + i] = blob[src + i];
+        };
+        put(kParConv0B * C, S.conv0_b, C);
+        put(kParQ1B * C, S.q1_b + MODE * C, C);
+        put(kParD1B * C, Br.d1_b, 2 * C);
+        put(kParGlnG * C, Br.gln_g, C);
+        put(kParGlnB * C, Br.gln_b, C);
+        put(kParD2B * C, Br.d2_b, C);
+        put(kParMixB * C, Br.mix_b, 64);
+        if (MODE == 1) {
+            put(kParQ2B * C + 64, S.q2_b, C);
+            put(kParR1B * C + 64, S.r1_b, C);
+            put(kParR2B * C + 64, S.r2_b, C);
+        }
+        __syncthreads();
+    }
 
     const int H = A.H, W = A.W;
     const int cols = W / 8 / P;
@@ -207,6 +398,46 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel16
         pix[p] = ((long)n * H + y) * W + x;
     }
 
+    // every Linear goes through G: chained LDS-ring version for C >= 64, per-wave streaming otherwise.
+    // The Linears of this kernel in execution order (the ring prefetches across them):
+    constexpr int NG = (MODE == 0) ? 6 : 10;
+    const char *bb = reinterpret_cast<const char *>(blob);
+    RingGemm seq[NG + 3];
+    {
+        constexpr int CH = NT / kRingNTC > 0 ? NT / kRingNTC : 1;
+        constexpr int KI = CIN / 32 > 0 ? CIN / 32 : 1;
+        int i = 0;
+        seq[i++] = RingGemm{bb + (size_t)S.conv0_w * 4, 0, KI, 0, KI, CH};
+        seq[i++] = RingGemm{bb + (size_t)S.q1_w * 4, MODE * NT, KS, 0, KS, CH};
+        seq[i++] = RingGemm{bb + (size_t)Br.d1_w * 4, 0, KS, 0, KS, CH};
+        seq[i++] = RingGemm{bb + (size_t)Br.d1_w * 4, NT, KS, 0, KS, CH};
+        seq[i++] = RingGemm{bb + (size_t)Br.mix_w * 4, 0, 2, 0, 2, BALF_MIX_RING ? 1 : 0};   // 64x64 token-mix matrix: 2 units
+        seq[i++] = RingGemm{bb + (size_t)Br.d2_w * 4, 0, KS, 0, KS, CH};
+        if (MODE == 1) {
+            seq[i++] = RingGemm{bb + (size_t)S.q2_w * 4, 0, 2 * KS, KS, KS, CH};
+            seq[i++] = RingGemm{bb + (size_t)S.q2_w * 4, 0, 2 * KS, 0, KS, CH};
+            seq[i++] = RingGemm{bb + (size_t)S.r1_w * 4, 0, KS, 0, KS, CH};
+            seq[i++] = RingGemm{bb + (size_t)S.r2_w * 4, 0, KS, 0, KS, CH};
+        }
+    }
+    seq[NG] = seq[0]; seq[NG + 1] = seq[0]; seq[NG + 2] = seq[0];    // padding (tot = 0, never issued)
+    int gu = 0;                                        // global ring unit counter (wave-uniform)
+    auto G = [&](auto idx, auto &acc, auto bload) {
+        constexpr int I = decltype(idx)::value;
+        const RingGemm &d = seq[I];
+        if constexpr (use_ring<C>()) {
+            const RingChain c = make_chain<NT>(seq[I], seq[I + 1], seq[I + 2], seq[I + 3], NG - I);
+            gemm16_chain<NT, P>(acc, c, gu, I == (CIN == 3 ? 1 : 0), lane, wave, ring, bload);
+        } else {
+            gemm16<NT, P>(acc, reinterpret_cast<const float *>(d.wbase), d.wnt0, d.KStot, d.ks0, d.ksn, lane, bload);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
+    using I8 = std::integral_constant<int, 8>; using I9 = std::integral_constant<int, 9>;
+
     // ---- x0 = relu(conv0(X)) ----
     f4 x0[NT][P];
     if constexpr (CIN == 3) {
@@ -220,7 +451,7 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel16
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const f4 bias = ldg4(blob + S.conv0_b + 16 * nt + 4 * q);
+            const f4 bias = ldg4(par + kParConv0B * C + 16 * nt + 4 * q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float *wr = blob + S.conv0_w + (16 * nt + 4 * q + r) * 3;
@@ -231,9 +462,27 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel16
             }
         }
     } else {
-        init_bias(x0, blob + S.conv0_b, q);
-        gemm16<NT, P>(x0, blob + S.conv0_w, 0, CIN / 32, 0, CIN / 32, lane,
-                      [&](int kk, int p) { return load_frag_px(A.X, pix[p], CIN, kk, q); });
+        init_bias(x0, par + kParConv0B * C, q);
+        if constexpr (use_ring<C>()) {
+            // B operand staged through the wave's slot first: ordinary global loads issued inside the ring
+            // loop would have to be waited for with vmcnt(0), which drains the LDS-DMA pipeline
+#pragma unroll
+            for (int kk = 0; kk < CIN / 32; ++kk)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const HL v = load_frag_px(A.X, pix[p], CIN, kk, q);
+                    slot[((kk * P + p) * 2 + 0) * 64 + lane] = v.hi;
+                    slot[((kk * P + p) * 2 + 1) * 64 + lane] = v.lo;
+                }
+            G(I0{}, x0, [&](int kk, int p) {
+                HL o;
+                o.hi = slot[((kk * P + p) * 2 + 0) * 64 + lane];
+                o.lo = slot[((kk * P + p) * 2 + 1) * 64 + lane];
+                return o;
+            });
+        } else {
+            G(I0{}, x0, [&](int kk, int p) { return load_frag_px(A.X, pix[p], CIN, kk, q); });
+        }
         relu(x0);
     }
 
@@ -249,8 +498,8 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel16
         return o;
     };
     f4 z[NT][P];
-    init_bias(z, blob + S.q1_b + MODE * C, q);
-    gemm16<NT, P>(z, blob + S.q1_w, MODE * NT, KS, 0, KS, lane, from_slot);
+    init_bias(z, par + kParQ1B * C, q);
+    G(I1{}, z, from_slot);
     gelu(z);
 
     {
@@ -259,16 +508,16 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel16
         store_slot16(slot, h, lane);
     }
     f4 ga[NT][P];
-    init_bias(ga, blob + Br.d1_b, q);
-    gemm16<NT, P>(ga, blob + Br.d1_w, 0, KS, 0, KS, lane, from_slot);
+    init_bias(ga, par + kParD1B * C, q);
+    G(I2{}, ga, from_slot);
     gelu(ga);
     {
         f4 gb[NT][P];
-        init_bias(gb, blob + Br.d1_b + C, q);
-        gemm16<NT, P>(gb, blob + Br.d1_w, NT, KS, 0, KS, lane, from_slot);
+        init_bias(gb, par + kParD1B * C + C, q);
+        G(I3{}, gb, from_slot);
         gelu(gb);
-        layernorm(gb, gb, blob + Br.gln_g, blob + Br.gln_b, q);
-        __syncthreads();
+        layernorm(gb, gb, par + kParGlnG * C, par + kParGlnB * C, q);
+        lds_barrier();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -282,14 +531,31 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel16
                 rowl[0] = l01[0]; rowl[kBtPitch16] = l01[1]; rowl[2 * kBtPitch16] = l23[0]; rowl[3 * kBtPitch16] = l23[1];
             }
     }
-    __syncthreads();
+    lds_barrier();
     {
         // mix^T[c][g'] = sum_g bT[c][g] * Wmix[g'][g]: A = bT rows (channels), B = natural-order Wmix fragments
-        const char *wm = reinterpret_cast<const char *>(blob + Br.mix_w) + (wave * 2) * 2048 + lane * 16;
         HL w0, w1;
-        w0.hi = *reinterpret_cast<const h8 *>(wm);        w0.lo = *reinterpret_cast<const h8 *>(wm + 1024);
-        w1.hi = *reinterpret_cast<const h8 *>(wm + 2048); w1.lo = *reinterpret_cast<const h8 *>(wm + 3072);
-        const float mb1 = blob[Br.mix_b + tok] + 1.0f;
+        if constexpr (use_ring<C>() && BALF_MIX_RING) {
+            // the mixing matrix arrives through the weight ring as chain entry 4 (two units of four 16-token
+            // row tiles); this wave needs row tile `wave` of each
+            const RingChain c = make_chain<NT>(seq[4], seq[5], seq[6], seq[7], NG - 4);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (BALF_RING_STRICT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // d2 follows: >= 2 units behind
+                chain_issue(c, ring, k + kRingSlots - 1, (gu + k + kRingSlots - 1) & (kRingSlots - 1), wave, lane);
+                const unsigned char *sl = ring + ((gu + k) & (kRingSlots - 1)) * kRingSlotBytes + wave * 2048 + lane * 16;
+                HL &w = k == 0 ? w0 : w1;
+                w.hi = *reinterpret_cast<const h8 *>(sl);
+                w.lo = *reinterpret_cast<const h8 *>(sl + 1024);
+            }
+            gu += 2;
+        } else {
+            const char *wm = reinterpret_cast<const char *>(blob + Br.mix_w) + (wave * 2) * 2048 + lane * 16;
+            w0.hi = *reinterpret_cast<const h8 *>(wm);        w0.lo = *reinterpret_cast<const h8 *>(wm + 1024);
+            w1.hi = *reinterpret_cast<const h8 *>(wm + 2048); w1.lo = *reinterpret_cast<const h8 *>(wm + 3072);
+        }
+        const float mb1 = par[kParMixB * C + tok] + 1.0f;
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
@@ -306,11 +572,11 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel16
                 for (int r = 0; r < 4; ++r) ga[ct][p][r] *= (m[r] + mb1);
             }
     }
-    __syncthreads();
+    lds_barrier();
     store_slot16(slot, ga, lane);
     f4 o[NT][P];
-    init_bias(o, blob + Br.d2_b, q);
-    gemm16<NT, P>(o, blob + Br.d2_w, 0, KS, 0, KS, lane, from_slot);
+    init_bias(o, par + kParD2B * C, q);
+    G(I5{}, o, from_slot);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -326,10 +592,26 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel16
     } else {
         store_slot16(slot, o, lane);
         f4 x1[NT][P];
-        init_bias(x1, blob + S.q2_b, q);
-        gemm16<NT, P>(x1, blob + S.q2_w, 0, 2 * KS, KS, KS, lane, from_slot);
-        gemm16<NT, P>(x1, blob + S.q2_w, 0, 2 * KS, 0, KS, lane,
-                      [&](int kk, int p) { return load_frag_px(A.U, pix[p], C, kk, q); });
+        init_bias(x1, par + kParQ2B * C + 64, q);
+        if constexpr (use_ring<C>()) {
+            HL ub[KS][P];                              // u' fragments: in flight during the v' half of dense2
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int p = 0; p < P; ++p) ub[kk][p] = load_frag_px(A.U, pix[p], C, kk, q);
+            G(I6{}, x1, from_slot);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    slot[((kk * P + p) * 2 + 0) * 64 + lane] = ub[kk][p].hi;
+                    slot[((kk * P + p) * 2 + 1) * 64 + lane] = ub[kk][p].lo;
+                }
+            G(I7{}, x1, from_slot);
+        } else {
+            G(I6{}, x1, from_slot);
+            G(I7{}, x1, [&](int kk, int p) { return load_frag_px(A.U, pix[p], C, kk, q); });
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -340,13 +622,13 @@ __global__ __launch_bounds__(256, (C >= 256 ? 1 : 2)) void stage_branch_kernel16
         layernorm_plain(x1, x1);
         store_slot16(slot, x1, lane);
         f4 m1[NT][P];
-        init_bias(m1, blob + S.r1_b, q);
-        gemm16<NT, P>(m1, blob + S.r1_w, 0, KS, 0, KS, lane, from_slot);
+        init_bias(m1, par + kParR1B * C + 64, q);
+        G(I8{}, m1, from_slot);
         lrelu(m1);
         store_slot16(slot, m1, lane);
         f4 t[NT][P];
-        init_bias(t, blob + S.r2_b, q);
-        gemm16<NT, P>(t, blob + S.r2_w, 0, KS, 0, KS, lane, from_slot);
+        init_bias(t, par + kParR2B * C + 64, q);
+        G(I9{}, t, from_slot);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f4 s = {0.0f, 0.0f, 0.0f, 0.0f};

@@ -68,6 +68,20 @@ def test_f16_split_vga_detections(model16):
     assert overlap > 0.97
 
 
+@pytest.mark.parametrize("shape", [(4, 512, 640), (2, 1088, 1920)])
+def test_f16_split_under_load_matches_fp32_path_and_is_deterministic(model, model16, shape):
+    """Enough workgroups to fill every CU twice over: the LDS weight ring of the f16 kernels (LDS-DMA +
+    counted waits + barriers) once had a write-after-read race that only showed with two workgroups per CU."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.rand(shape[0], 3, shape[1], shape[2], generator=g).to("cuda:0")
+    with torch.inference_mode():
+        ref = model(x)["prob"]
+        a = model16(x)["prob"]
+        b = model16(x)["prob"]
+    assert torch.equal(a, b)
+    assert (a - ref).abs().max().item() < 2e-5
+
+
 def test_f16_split_determinism_and_batch_invariance(model16):
     x = cases.forward_input(3, 128, 192, 99).to("cuda:0")
     with torch.inference_mode():

@@ -1,0 +1,24 @@
+"""Per-kernel ms for one precision (development aid): python tools/bench_kernels.py fp16|fp32"""
+import sys
+import torch
+sys.path.insert(0, ".")
+from balf_amd import arch, ops
+from balf_amd.model import get_model
+from balf_amd.utils import synth
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+m.load_state_dict(synth.synthetic_state_dict(1))
+m.precision = prec
+m = m.eval().cuda()
+x = torch.rand((8, 3, 1088, 1920), device="cuda")
+for _ in range(2):
+    m(x, want_logits=False)
+torch.cuda.synchronize()
+ops.profile_begin()
+n = 3
+for _ in range(n):
+    m(x, want_logits=False)
+torch.cuda.synchronize()
+prof = ops.profile_end()
+tot = sum(v[0] for v in prof.values()) / n
+print(prec, "total %.2f ms / 8 img -> %.1f img/s" % (tot, 8 / tot * 1e3), " ".join(f"{k.replace('stage','s').replace('_branch','')}={v[0]/n:.2f}" for k, v in sorted(prof.items())))
