@@ -7,7 +7,12 @@ grayscale images already resident in HBM (gray replicated to 3 channels, /255, p
 SURVEY.md F4/F5).  Workload = BASELINE.json configs[3] divided over the node: 32 images per GPU
 (256 over 8 GPUs), top-2000, border 15, nms 15; weak scaling.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|fp16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp16|fp32]
+
+--precision fp16 (default) = f16 MFMA with split (hi+lo) operands, three products per tile, fp32
+accumulate/LayerNorm/GELU/softmax/NMS: score map within 5e-6 of the reference (north-star bar 1e-4).
+--precision fp32 = exact fp32 MFMA.  The other precision is also run (untimed headline, timed on its own)
+and reported under "other_precision".
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `value` = images/s over all GPUs; `keypoints_per_s` rides along.
@@ -49,6 +54,19 @@ def stage_macs_per_pixel(s: int):
     return grid, block
 
 
+def kernel_bytes_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
+    """Algorithmic HBM bytes per launch of a branch kernel: what it must read and write once
+    (DESIGN.md 4.1 table): grid: stage input + u'; block: stage input + u' + t + r."""
+    if not (name.startswith("stage") and "branch" in name):
+        return 0.0
+    s = int(name[5]) - 1
+    c = [32, 64, 128, 256][s]
+    cin = [3, 32, 64, 128][s]
+    px = mb * (hp >> s) * (wp >> s)
+    per_px = 4.0 * (cin + c) if "grid" in name else 4.0 * (cin + c + 2 * c)
+    return per_px * px
+
+
 def kernel_flops_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
     if name.startswith("stage") and ("grid_branch" in name or "block_branch" in name):
         s = int(name[5]) - 1
@@ -60,11 +78,14 @@ def kernel_flops_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
     return 0.0
 
 
-def cpu_baseline(h, w, k, n_images, state):
-    """The CPU oracle (port of the reference path) on `n_images` of the same workload."""
+def cpu_baseline(h, w, k, n_images, state, threads=0):
+    """The CPU oracle (port of the reference path) on `n_images` of the same workload.  The path is
+    layout/elementwise-bound on the CPU and slows down past a few dozen threads, so the
+    thread count is capped (256 threads measured 34 s/image on the GPU box, 8 threads 6.6 s in the build
+    container)."""
     from oracle import oracle as O
     from oracle import c_oracle
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(threads if threads > 0 else min(os.cpu_count() or 1, 32))
     imgs = np.stack([synth.gray_to_rgb_norm(synth.synthetic_gray_u8(h, w, i)) for i in range(n_images)])
     t0 = time.perf_counter()
     kp = 0
@@ -88,7 +109,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--precision", default="fp16", choices=["fp32", "fp16"])
+    ap.add_argument("--other-steps", type=int, default=2, help="timed steps of the other precision (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cores, 32))")
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
@@ -137,62 +160,95 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        out = step()
-    fence()
-    ops.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = ops.profile_end()
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    counts = out[2]
-    kp_per_image = float(counts.float().mean().item())
+    def timed_run(steps, warmup):
+        for _ in range(warmup):
+            o = step()
+        fence()
+        ops.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o = step()
+        fence()
+        dt_ = time.perf_counter() - t0
+        prof_ = ops.profile_end()
+        if dist is not None:
+            tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax.item())
+        return dt_, prof_, o
 
-    if rank == 0:
-        images = world * b * args.steps
-        ips = images / dt
-        # dominant kernel by device time
-        name, (ms, n_launch) = max(prof.items(), key=lambda kv: kv[1][0])
-        mb = max(1, min(b, 16 * 1024 * 1024 // (hp * wp)))      # images per launch (make_plan in detector.hip)
-        launches_per_step = -(-b // mb)
+    mb = max(1, min(b, 16 * 1024 * 1024 // (hp * wp)))          # images per launch (make_plan in det_common.h)
+
+    def summarize(precision, dt_, prof_, steps):
+        """images/s + the roofline of the dominant kernel: whichever of the MFMA and HBM roofs it sits closer to."""
+        name, (ms, n_launch) = max(prof_.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / n_launch
         flops = kernel_flops_per_launch(name, mb, hp, wp)
-        peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_FP16_MFMA_TFLOPS
-        achieved = flops / (avg_ms * 1e-3) / 1e12 if flops else 0.0
-        fwd_ms = sum(v[0] for kname, v in prof.items() if kname.startswith("stage")) / args.steps
-        nms_ms = sum(v[0] for kname, v in prof.items() if not kname.startswith("stage")) / args.steps
+        nbytes = kernel_bytes_per_launch(name, mb, hp, wp)
+        # f16 path: every algorithmic MAC costs three f16 MFMA products (hi*hi + lo*hi + hi*lo)
+        peak_tf = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_FP16_MFMA_TFLOPS / 3.0
+        tf = flops / (avg_ms * 1e-3) / 1e12 if flops else 0.0
+        gbs = nbytes / (avg_ms * 1e-3) / 1e9 if nbytes else 0.0
+        f_m, f_h = tf / peak_tf, gbs / PEAK_HBM_GBS
+        roof = {"kernel": name, "avg_launch_ms": avg_ms, "launches": n_launch, "images_per_launch": mb,
+                "traffic": None,
+                "mfma": {"achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": f_m,
+                         "algorithmic_flop_per_launch": flops},
+                "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h,
+                        "algorithmic_bytes_per_launch": nbytes}}
+        if f_m >= f_h:
+            roof.update({"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": f_m})
+        else:
+            roof.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h})
+        fwd_ms = sum(v[0] for kname, v in prof_.items() if kname.startswith("stage")) / steps
+        nms_ms = sum(v[0] for kname, v in prof_.items() if not kname.startswith("stage")) / steps
+        return {"images_per_s": world * b * steps / dt_, "ms_per_step": dt_ / steps * 1e3, "roofline": roof,
+                "forward_device_ms_per_step": fwd_ms, "nms_topk_device_ms_per_step": nms_ms,
+                "forward_tflops": b * hp * wp * arch.FLOP_PER_PADDED_PIXEL / (fwd_ms * 1e-3) / 1e12,
+                "kernels_ms_per_step": {kname: v[0] / steps for kname, v in sorted(prof_.items())}}
+
+    dt, prof, out = timed_run(args.steps, args.warmup)
+    counts = out[2]
+    kp_per_image = float(counts.float().mean().item())
+    head = summarize(args.precision, dt, prof, args.steps)
+
+    other = None
+    other_prec = "fp32" if args.precision == "fp16" else "fp16"
+    if args.other_steps > 0:
+        model.precision = other_prec
+        dt2, prof2, _ = timed_run(args.other_steps, 1)
+        other = summarize(other_prec, dt2, prof2, args.other_steps)
+        other["precision"] = other_prec
+        model.precision = args.precision
+
+    if rank == 0:
+        ips = head["images_per_s"]
         nms_bytes = b * (4.0 * h * w + 8.0 * k + 4.0)
+        nms_ms = head["nms_topk_device_ms_per_step"]
+        dtype = ("f16 MFMA, split hi+lo operands (3 products), f32 accumulate/LN/GELU/softmax/NMS"
+                 if args.precision == "fp16" else "f32")
         res = {
             "metric": "images/sec + keypoints/sec on 1080p gray (detector forward + NMS + top-K)",
             "value": ips, "unit": "images/s", "keypoints_per_s": ips * kp_per_image,
             "keypoints_per_image": kp_per_image,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f16 MFMA operands, f32 accumulate/LN/GELU/softmax/NMS",
-            "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{b} images/GPU x {world} GPU, {w}x{h} gray -> [B,3,{hp},{wp}] fp32, top-{k}, "
-                                   f"border 15, nms 15 (BASELINE configs[3] shard)",
-                       "global_batch": b * world, "parallelism": f"dp{world}",
+                                   f"border 15, nms 15 (BASELINE configs[3]/[4] shard)",
+                       "global_batch": b * world, "parallelism": f"dp{world}", "precision": args.precision,
                        "collective": "all_gather of [B,2K+1] int32 keypoint slabs" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
-                         "avg_launch_ms": avg_ms, "launches": n_launch, "images_per_launch": mb,
-                         "algorithmic_flop_per_launch": flops},
-            "forward_device_ms_per_step": fwd_ms, "nms_topk_device_ms_per_step": nms_ms,
-            "forward_tflops": b * hp * wp * arch.FLOP_PER_PADDED_PIXEL / (fwd_ms * 1e-3) / 1e12,
-            "forward_frac_of_mfma_peak": b * hp * wp * arch.FLOP_PER_PADDED_PIXEL / (fwd_ms * 1e-3) / 1e12 / peak,
+            "roofline": head["roofline"],
+            "forward_device_ms_per_step": head["forward_device_ms_per_step"],
+            "nms_topk_device_ms_per_step": nms_ms,
+            "forward_tflops": head["forward_tflops"],
             "nms_topk_roofline": {"bound": "hbm", "achieved": nms_bytes / (nms_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                                   "unit": "GB/s", "frac": nms_bytes / (nms_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
-            "kernels_ms_per_step": {kname: v[0] / args.steps for kname, v in sorted(prof.items())},
+            "kernels_ms_per_step": head["kernels_ms_per_step"],
+            "other_precision": other,
         }
         if world == 1 and args.cpu_images > 0:
-            res["cpu_baseline"] = cpu_baseline(h, w, k, args.cpu_images, state)
+            res["cpu_baseline"] = cpu_baseline(h, w, k, args.cpu_images, state, args.cpu_threads)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
