@@ -69,14 +69,45 @@ __device__ __forceinline__ float gelu1(float x) {
     return fmaf(ax, 0.5f - y, 0.5f * x);           // = max(x, 0) - |x| y:  x >= 0: x(1 - y);  x < 0: x y
 }
 
-template <int NT, int P>
+// GELU on four values with the multiply/add work written as 2-wide vector math, which hipcc lowers to
+// v_pk_mul_f32 / v_pk_fma_f32 (two fp32 lanes per VALU slot; a wave64 VALU instruction occupies the SIMD for
+// 4 cycles either way, so packing halves the cost of everything but the rcp/exp2).
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 gelu2(f2 x) {
+    const f2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f2 den = ax * (0.3275911f * 0.70710678118654752440f) + 1.0f;
+    const f2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f2 ea = x * x * (-0.5f * 1.44269504088896340736f);
+    const f2 e = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+    f2 p = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+    p = p * t + (0.5f * 1.421413741f);
+    p = p * t + (0.5f * -0.284496736f);
+    p = p * t + (0.5f * 0.254829592f);
+    const f2 y = p * t * e;                         // Phi(-|x|)
+    return ax * (0.5f - y) + x * 0.5f;
+}
+
+#ifndef BALF_ABLATE_GELU
+#define BALF_ABLATE_GELU 0
+#endif
+// PACKED: 2-wide vector math (v_pk_*): fewer VALU slots, but the register pairs it needs cost more than they
+// save in the register-starved kernels (block branch, C = 256) -- measured per kernel, see DESIGN.md.
+template <bool PACKED = true, int NT, int P>
 __device__ __forceinline__ void gelu(f4 (&t)[NT][P]) {
+    if (BALF_ABLATE_GELU) return;                // timing experiment only
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int p = 0; p < P; ++p)
+        for (int p = 0; p < P; ++p) {
+            if constexpr (PACKED) {
+                const f2 lo = gelu2(f2{t[nt][p][0], t[nt][p][1]}), hi = gelu2(f2{t[nt][p][2], t[nt][p][3]});
+                t[nt][p] = f4{lo[0], lo[1], hi[0], hi[1]};
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[nt][p][r] = gelu1(t[nt][p][r]);
+                for (int r = 0; r < 4; ++r) t[nt][p][r] = gelu1(t[nt][p][r]);
+            }
+        }
 }
 
 template <int NT, int P>
@@ -108,49 +139,15 @@ __device__ __forceinline__ float quarter_allreduce(float v) {   // the 4 lanes l
     return v;
 }
 
-// LayerNorm over the channel axis (eps 1e-5, affine), y may alias x.
-template <int NT, int P>
-__device__ __forceinline__ void layernorm(const f4 (&x)[NT][P], f4 (&y)[NT][P], const float *g, const float *b,
-                                          int q) {
+// LayerNorm over the channel axis (eps 1e-5, affine), y may alias x.  4-wide vector math (-> packed VALU).
+template <bool PACKED = true, int NT, int P>
+__device__ __forceinline__ void ln_stats(const f4 (&x)[NT][P], int p, float &mean, float &rstd) {
     constexpr float inv_c = 1.0f / (16 * NT);
-    float mean[P], rstd[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
+    if constexpr (!PACKED) {
         float s = 0.0f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) s += (x[nt][p][0] + x[nt][p][1]) + (x[nt][p][2] + x[nt][p][3]);
-        mean[p] = quarter_allreduce(s) * inv_c;
-        float v = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = x[nt][p][r] - mean[p];
-                v += d * d;
-            }
-        rstd[p] = __builtin_amdgcn_rsqf(quarter_allreduce(v) * inv_c + kLnEps);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const f4 gg = ldg4(g + 16 * nt + 4 * q), bb = ldg4(b + 16 * nt + 4 * q);
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[nt][p][r] = (x[nt][p][r] - mean[p]) * rstd[p] * gg[r] + bb[r];
-    }
-}
-
-// LayerNorm without the affine part: (x - mean) * rstd.  Used where gamma/beta were folded into the
-// weights/bias of the Linear that consumes the result (weights.hip: fold_ln).
-template <int NT, int P>
-__device__ __forceinline__ void layernorm_plain(const f4 (&x)[NT][P], f4 (&y)[NT][P]) {
-    constexpr float inv_c = 1.0f / (16 * NT);
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        float s = 0.0f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) s += (x[nt][p][0] + x[nt][p][1]) + (x[nt][p][2] + x[nt][p][3]);
-        const float mean = quarter_allreduce(s) * inv_c;
+        mean = quarter_allreduce(s) * inv_c;
         float v = 0.0f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -159,12 +156,57 @@ __device__ __forceinline__ void layernorm_plain(const f4 (&x)[NT][P], f4 (&y)[NT
                 const float d = x[nt][p][r] - mean;
                 v = fmaf(d, d, v);
             }
-        const float rstd = __builtin_amdgcn_rsqf(quarter_allreduce(v) * inv_c + kLnEps);
+        rstd = __builtin_amdgcn_rsqf(quarter_allreduce(v) * inv_c + kLnEps);
+        return;
+    }
+    f4 s4 = x[0][p];
+#pragma unroll
+    for (int nt = 1; nt < NT; ++nt) s4 += x[nt][p];
+    mean = quarter_allreduce((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_c;
+    f4 v4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const f4 d = x[nt][p] - mean;
+        v4 += d * d;
+    }
+    rstd = __builtin_amdgcn_rsqf(quarter_allreduce((v4[0] + v4[1]) + (v4[2] + v4[3])) * inv_c + kLnEps);
+}
+
+template <bool PACKED = true, int NT, int P>
+__device__ __forceinline__ void layernorm(const f4 (&x)[NT][P], f4 (&y)[NT][P], const float *g, const float *b,
+                                          int q) {
+    float mean[P], rstd[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) ln_stats<PACKED>(x, p, mean[p], rstd[p]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const f4 gg = ldg4(g + 16 * nt + 4 * q), bb = ldg4(b + 16 * nt + 4 * q);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if constexpr (PACKED) y[nt][p] = (x[nt][p] - mean[p]) * (gg * rstd[p]) + bb;
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[nt][p][r] = (x[nt][p][r] - mean[p]) * rstd[p] * gg[r] + bb[r];
+        }
+    }
+}
+
+// LayerNorm without the affine part: (x - mean) * rstd.  Used where gamma/beta were folded into the
+// weights/bias of the Linear that consumes the result (weights.hip: fold_ln).
+template <bool PACKED = true, int NT, int P>
+__device__ __forceinline__ void layernorm_plain(const f4 (&x)[NT][P], f4 (&y)[NT][P]) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        float mean, rstd;
+        ln_stats<PACKED>(x, p, mean, rstd);
         const float shift = -mean * rstd;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (PACKED) y[nt][p] = x[nt][p] * rstd + shift;
+            else
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[nt][p][r] = fmaf(x[nt][p][r], rstd, shift);
+                for (int r = 0; r < 4; ++r) y[nt][p][r] = fmaf(x[nt][p][r], rstd, shift);
+        }
     }
 }
 

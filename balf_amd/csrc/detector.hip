@@ -98,6 +98,7 @@ __device__ __forceinline__ void gemm(f4 (&acc)[NTT][P], const float *w, int wnt0
 
 template <int C, int CIN, int MODE>
 __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(StageArgs A) {
+    constexpr bool PK = (MODE == 0) && (C == 32);      // packed VALU math only where it measured faster
     constexpr int P = StageP<C>::P;
     constexpr int NT = C / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -162,31 +163,31 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(Stage
     // ---- z = GELU(dense1[MODE half](LN(x0))) : u (grid) or v (block) ----
     {
         f4 h[NT][P];
-        layernorm_plain(x0, h);                        // q.norm affine folded into dense1
+        layernorm_plain<PK>(x0, h);                        // q.norm affine folded into dense1
         store_slot(slot, h, lane);
     }
     auto from_slot = [&](int kk, int p) { return slot[(kk * P + p) * 64 + lane]; };
     f4 z[NT][P];
     init_bias(z, blob + S.q1_b + MODE * C, q);
     gemm<NT, P>(z, blob + S.q1_w, MODE * NT, NT, 0, NT, lane, from_slot);
-    gelu(z);
+    gelu<PK>(z);
 
     // ---- gMLP branch on z ----
     {
         f4 h[NT][P];
-        layernorm_plain(z, h);                         // branch .norm affine folded into its dense1
+        layernorm_plain<PK>(z, h);                         // branch .norm affine folded into its dense1
         store_slot(slot, h, lane);
     }
     f4 ga[NT][P];                                      // gate input a = first C outputs of dense1
     init_bias(ga, blob + Br.d1_b, q);
     gemm<NT, P>(ga, blob + Br.d1_w, 0, NT, 0, NT, lane, from_slot);
-    gelu(ga);
+    gelu<PK>(ga);
     {
         f4 gb[NT][P];                                  // b = last C outputs, normalised, then token-mixed
         init_bias(gb, blob + Br.d1_b + C, q);
         gemm<NT, P>(gb, blob + Br.d1_w, NT, NT, 0, NT, lane, from_slot);
-        gelu(gb);
-        layernorm(gb, gb, blob + Br.gln_g, blob + Br.gln_b, q);
+        gelu<PK>(gb);
+        layernorm<PK>(gb, gb, blob + Br.gln_g, blob + Br.gln_b, q);
         __syncthreads();                               // every wave is done reading its slot
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(Stage
                 *reinterpret_cast<f4 *>(A.R + pix[p] * C + 16 * nt + 4 * q) = x1[nt][p] + x0[nt][p];
             }
         // ---- t = conv2(lrelu(conv1(LN(x1)))) ----
-        layernorm_plain(x1, x1);                       // RCAB .norm affine folded into conv1
+        layernorm_plain<PK>(x1, x1);                       // RCAB .norm affine folded into conv1
         store_slot(slot, x1, lane);
         f4 m1[NT][P];
         init_bias(m1, blob + S.r1_b, q);

@@ -252,6 +252,58 @@ __device__ __forceinline__ void chain_issue(const RingChain &c, unsigned char *r
     __builtin_amdgcn_global_load_lds((glb_void *)(src + 1024), (lds_void *)(dst + 1024), 16, 0, 0);
 }
 
+// Protocol (global unit index G, 4 slots, slot = G & 3); iteration G:
+//   s_waitcnt vmcnt  -> this wave's DMA of unit G has landed (units G+1, G+2 may still be in flight);
+//   lgkmcnt(0)       -> this wave's ds_reads of unit G-1 have returned (hipcc sinks the MFMAs that consume
+//                       them, and their wait, below the barrier; without this the re-fill of that slot raced
+//                       with the reads when two workgroups shared a CU);
+//   s_barrier        -> every wave's part of unit G is visible, nobody reads slot (G-1) & 3 any more;
+//   issue DMA of unit G+3 into slot (G-1) & 3;  ds_read unit G;  MFMAs.
+// (A variant that read unit G+1's fragments during unit G's MFMAs measured no faster and costs 32 VGPRs.)
+__device__ __forceinline__ void ring_wait_barrier(int after /* units issued after the awaited one */) {
+    // wait + barrier are ONE asm statement with a memory clobber: the raw s_barrier builtin is IntrNoMem, so
+    // the compiler could otherwise move LDS accesses across it
+    if (BALF_RING_STRICT || after <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (after == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NTC>
+__device__ __forceinline__ void ring_read(HL (&a)[NTC], const unsigned char *ring, int g, int lane) {
+    const unsigned char *slot = ring + (g & (kRingSlots - 1)) * kRingSlotBytes + lane * 16;
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) {
+        a[nt].hi = *reinterpret_cast<const h8 *>(slot + nt * 2048);
+        a[nt].lo = *reinterpret_cast<const h8 *>(slot + nt * 2048 + 1024);
+    }
+}
+
+#ifndef BALF_ABLATE_MFMA
+#define BALF_ABLATE_MFMA 0
+#endif
+template <int NTT, int CI, int P>
+__device__ __forceinline__ void ring_mfma(f4 (&acc)[NTT][P], const HL (&a)[kRingNTC], const HL (&b)[P]) {
+    if (BALF_ABLATE_MFMA) {                      // timing experiment: keep the operands alive, skip the MFMAs
+#pragma unroll
+        for (int nt = 0; nt < kRingNTC; ++nt) asm volatile("" ::"v"(a[nt].hi), "v"(a[nt].lo));
+#pragma unroll
+        for (int p = 0; p < P; ++p) asm volatile("" ::"v"(b[p].hi), "v"(b[p].lo));
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < kRingNTC; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[CI * kRingNTC + nt][p] = mfma16(a[nt].lo, b[p].hi, acc[CI * kRingNTC + nt][p]);
+#pragma unroll
+    for (int nt = 0; nt < kRingNTC; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[CI * kRingNTC + nt][p] = mfma16(a[nt].hi, b[p].lo, acc[CI * kRingNTC + nt][p]);
+#pragma unroll
+    for (int nt = 0; nt < kRingNTC; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[CI * kRingNTC + nt][p] = mfma16(a[nt].hi, b[p].hi, acc[CI * kRingNTC + nt][p]);
+}
+
 template <int NTT, int CI, int P, typename BL>
 __device__ __forceinline__ void chain_chunk(f4 (&acc)[NTT][P], const RingChain &c, unsigned char *ring, int gu,
                                             int lane, int wave, BL bload) {
@@ -260,59 +312,28 @@ __device__ __forceinline__ void chain_chunk(f4 (&acc)[NTT][P], const RingChain &
         const int later = c.tot[1] + c.tot[2] + c.tot[3];
         for (int k = 0; k < ksn; ++k) {
             const int u = CI * ksn + k;
-            const int after = c.tot[0] - 1 - u + later;      // units issued after u, capped at slots - 2
-            // wait + barrier as ONE asm statement with a memory clobber: the raw s_barrier builtin is
-            // IntrNoMem, i.e. the compiler may otherwise hoist the ring's ds_reads above it.  lgkmcnt(0)
-            // retires this wave's ds_reads of slot (u-1)%4 BEFORE the barrier: hipcc sinks the MFMAs that
-            // consume them (and their lgkmcnt wait) below the barrier, and the slot is re-filled by DMA right
-            // after it -- without this, two workgroups per CU produced wrong tiles under load (WAR race)
-            if (BALF_RING_STRICT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (after >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (after == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            ring_wait_barrier(c.tot[0] - 1 - u + later);
             chain_issue(c, ring, u + kRingSlots - 1, (gu + u + kRingSlots - 1) & (kRingSlots - 1), wave, lane);
-            const unsigned char *slot = ring + ((gu + u) & (kRingSlots - 1)) * kRingSlotBytes + lane * 16;
             HL a[kRingNTC], b[P];
-#pragma unroll
-            for (int nt = 0; nt < kRingNTC; ++nt) {
-                a[nt].hi = *reinterpret_cast<const h8 *>(slot + nt * 2048);
-                a[nt].lo = *reinterpret_cast<const h8 *>(slot + nt * 2048 + 1024);
-            }
+            ring_read<kRingNTC>(a, ring, gu + u, lane);
 #pragma unroll
             for (int p = 0; p < P; ++p) b[p] = bload(k, p);
-#pragma unroll
-            for (int nt = 0; nt < kRingNTC; ++nt)
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    acc[CI * kRingNTC + nt][p] = mfma16(a[nt].lo, b[p].hi, acc[CI * kRingNTC + nt][p]);
-#pragma unroll
-            for (int nt = 0; nt < kRingNTC; ++nt)
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    acc[CI * kRingNTC + nt][p] = mfma16(a[nt].hi, b[p].lo, acc[CI * kRingNTC + nt][p]);
-#pragma unroll
-            for (int nt = 0; nt < kRingNTC; ++nt)
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    acc[CI * kRingNTC + nt][p] = mfma16(a[nt].hi, b[p].hi, acc[CI * kRingNTC + nt][p]);
+            ring_mfma<NTT, CI, P>(acc, a, b);
         }
         chain_chunk<NTT, CI + 1, P>(acc, c, ring, gu, lane, wave, bload);
     }
 }
 
-// Run chain.g[0].  `gu` = global index of its unit 0 (advanced by the caller); `first` = nothing has been
-// issued yet (first GEMM of the kernel): prime global units 0..2.  All four waves call this together.
+// Run chain.g[0].  `gu` = global index of its unit 0 (advanced here).  All four waves call this together;
+// the first three units of the kernel's sequence were issued in the prologue.
 template <int NTT, int P, typename BL>
-__device__ __forceinline__ void gemm16_chain(f4 (&acc)[NTT][P], const RingChain &c, int &gu, bool first, int lane,
-                                             int wave, unsigned char *ring, BL bload) {
+__device__ __forceinline__ void gemm16_chain(f4 (&acc)[NTT][P], const RingChain &c, int &gu, int lane, int wave,
+                                             unsigned char *ring, BL bload) {
     static_assert(NTT % kRingNTC == 0, "row tiles must come in groups of 4");
-    if (first)
-        for (int t = 0; t < kRingSlots - 1; ++t) chain_issue(c, ring, t, (gu + t) & (kRingSlots - 1), wave, lane);
     chain_chunk<NTT, 0, P>(acc, c, ring, gu, lane, wave, bload);
     gu += c.tot[0];
 }
 
-// workgroup barrier that orders LDS traffic only: no vmcnt(0), so LDS-DMA prefetches stay in flight
 #ifndef BALF_RAW_LDS_BARRIER
 #define BALF_RAW_LDS_BARRIER 1
 #endif
@@ -322,6 +343,42 @@ __device__ __forceinline__ void gemm16_chain(f4 (&acc)[NTT][P], const RingChain 
 __device__ __forceinline__ void lds_barrier() {
     if (BALF_RAW_LDS_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else __syncthreads();
+}
+
+// Stage 1 (C = 32): every Linear is ONE K-step of two weight row-tiles.  Their fragments are loaded one Linear
+// ahead (during the previous epilogue) so that no L2 round trip sits between an epilogue and the next MFMAs.
+struct WPre {
+    HL a[2];
+};
+
+__device__ __forceinline__ WPre wpre_load(const RingGemm &d, int lane) {
+    const char *p = d.wbase + ((size_t)d.wnt0 * d.KStot + d.ks0) * 2048 + lane * 16;
+    WPre w;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        w.a[nt].hi = *reinterpret_cast<const h8 *>(p + (size_t)nt * d.KStot * 2048);
+        w.a[nt].lo = *reinterpret_cast<const h8 *>(p + (size_t)nt * d.KStot * 2048 + 1024);
+    }
+    return w;
+}
+
+template <int P, typename BL>
+__device__ __forceinline__ void gemm16_single(f4 (&acc)[2][P], const WPre &w, BL bload) {
+    HL b[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) b[p] = bload(0, p);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[nt][p] = mfma16(w.a[nt].lo, b[p].hi, acc[nt][p]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[nt][p] = mfma16(w.a[nt].hi, b[p].lo, acc[nt][p]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[nt][p] = mfma16(w.a[nt].hi, b[p].hi, acc[nt][p]);
 }
 
 constexpr int kBtPitch16 = kTokens + 8;        // halves per channel row of the transposed token tile
@@ -347,6 +404,7 @@ constexpr int stage_lds_bytes16() {
 
 template <int C, int CIN, int MODE>
 __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(StageArgs A) {
+    constexpr bool PK = (MODE == 0) && (C == 32);      // packed VALU math only where it measured faster
     constexpr int P = StageP<C>::P;
     constexpr int NT = C / 16, KS = C / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -362,25 +420,6 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     const float *blob = A.blob;
     const StageOff &S = A.off;
     const BranchOff &Br = S.br[MODE];
-
-    {   // parameter cache (see par_floats)
-        auto put = [&](int dst, int src, int n) {
-            for (int i = threadIdx.x; i < n; i += 256) par[dst + i] = blob[src + i];
-        };
-        put(kParConv0B * C, S.conv0_b, C);
-        put(kParQ1B * C, S.q1_b + MODE * C, C);
-        put(kParD1B * C, Br.d1_b, 2 * C);
-        put(kParGlnG * C, Br.gln_g, C);
-        put(kParGlnB * C, Br.gln_b, C);
-        put(kParD2B * C, Br.d2_b, C);
-        put(kParMixB * C, Br.mix_b, 64);
-        if (MODE == 1) {
-            put(kParQ2B * C + 64, S.q2_b, C);
-            put(kParR1B * C + 64, S.r1_b, C);
-            put(kParR2B * C + 64, S.r2_b, C);
-        }
-        __syncthreads();
-    }
 
     const int H = A.H, W = A.W;
     const int cols = W / 8 / P;
@@ -398,8 +437,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
         pix[p] = ((long)n * H + y) * W + x;
     }
 
-    // every Linear goes through G: chained LDS-ring version for C >= 64, per-wave streaming otherwise.
-    // The Linears of this kernel in execution order (the ring prefetches across them):
+    // the Linears of this kernel in execution order (the weight ring prefetches across them)
     constexpr int NG = (MODE == 0) ? 6 : 10;
     const char *bb = reinterpret_cast<const char *>(blob);
     RingGemm seq[NG + 3];
@@ -422,12 +460,86 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     }
     seq[NG] = seq[0]; seq[NG + 1] = seq[0]; seq[NG + 2] = seq[0];    // padding (tot = 0, never issued)
     int gu = 0;                                        // global ring unit counter (wave-uniform)
+
+    // ---- kernel prologue: put every long-latency request in flight before the first wait ----
+    //  (1) this lane's stage-1 input pixels (NCHW planes), (2) one dword of every u' row the block kernel will
+    //  read much later (pulls the lines into L2), (3) the first three weight units of the ring, (4) the
+    //  per-channel parameters for the LDS cache; only then the barrier that publishes the cache.
+    float in[P][3];
+    if constexpr (CIN == 3) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const long hw = (long)H * W;
+            const long o = pix[p] - (long)n * hw;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) in[p][k] = A.X[((long)n * 3 + k) * hw + o];
+        }
+    }
+    if constexpr (use_ring<C>() && CIN != 3) {
+        // stage input as the first Linear's B operand, staged through the wave's slot: an ordinary global
+        // load issued inside the ring loop would have to be waited for with a vmcnt that drains the LDS-DMA queue
+        HL xin[CIN / 32][P];
+#pragma unroll
+        for (int kk = 0; kk < CIN / 32; ++kk)
+#pragma unroll
+            for (int p = 0; p < P; ++p) xin[kk][p] = load_frag_px(A.X, pix[p], CIN, kk, q);
+#pragma unroll
+        for (int kk = 0; kk < CIN / 32; ++kk)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                slot[((kk * P + p) * 2 + 0) * 64 + lane] = xin[kk][p].hi;
+                slot[((kk * P + p) * 2 + 1) * 64 + lane] = xin[kk][p].lo;
+            }
+    }
+    float touch = 0.0f;
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) touch += A.U[pix[p] * C + 32 * kk + 8 * q];
+    }
+    if constexpr (use_ring<C>()) {
+        const RingChain c0 = make_chain<NT>(seq[0], seq[1], seq[2], seq[3], NG);
+#pragma unroll
+        for (int t = 0; t < kRingSlots - 1; ++t) chain_issue(c0, ring, t, t, wave, lane);
+    }
+    {   // parameter cache (see par_floats)
+        auto put = [&](int dst, int src, int n) {
+            for (int i = threadIdx.x; i < n; i += 256) par[dst + i] = blob[src + i];
+        };
+        put(kParConv0B * C, S.conv0_b, C);
+        put(kParQ1B * C, S.q1_b + MODE * C, C);
+        put(kParD1B * C, Br.d1_b, 2 * C);
+        put(kParGlnG * C, Br.gln_g, C);
+        put(kParGlnB * C, Br.gln_b, C);
+        put(kParD2B * C, Br.d2_b, C);
+        put(kParMixB * C, Br.mix_b, 64);
+        if (MODE == 1) {
+            put(kParQ2B * C + 64, S.q2_b, C);
+            put(kParR1B * C + 64, S.r1_b, C);
+            put(kParR2B * C + 64, S.r2_b, C);
+        }
+        __syncthreads();
+    }
+
+
+    WPre wpre;                                         // stage 1: weights of the next Linear
+    if constexpr (!use_ring<C>() && NT == 2) wpre = wpre_load(seq[1], lane);
+    // every Linear goes through G: chained LDS-ring version for C >= 64, per-wave streaming otherwise.
+    // The Linears of this kernel in execution order (the ring prefetches across them):
     auto G = [&](auto idx, auto &acc, auto bload) {
         constexpr int I = decltype(idx)::value;
         const RingGemm &d = seq[I];
         if constexpr (use_ring<C>()) {
             const RingChain c = make_chain<NT>(seq[I], seq[I + 1], seq[I + 2], seq[I + 3], NG - I);
-            gemm16_chain<NT, P>(acc, c, gu, I == (CIN == 3 ? 1 : 0), lane, wave, ring, bload);
+            gemm16_chain<NT, P>(acc, c, gu, lane, wave, ring, bload);            // ring primed in the prologue
+        } else if constexpr (NT == 2) {
+            gemm16_single<P>(acc, wpre, bload);
+            constexpr int NX = (I + 1 == 4) ? I + 2 : I + 1;          // entry 4 is the token-mix matrix
+            if constexpr (NX < NG) {
+                wpre = wpre_load(seq[NX], lane);
+                __builtin_amdgcn_sched_barrier(0);                     // keep the loads ahead of the epilogue
+            }
         } else {
             gemm16<NT, P>(acc, reinterpret_cast<const float *>(d.wbase), d.wnt0, d.KStot, d.ks0, d.ksn, lane, bload);
         }
@@ -440,15 +552,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
 
     // ---- x0 = relu(conv0(X)) ----
     f4 x0[NT][P];
-    if constexpr (CIN == 3) {
-        float in[P][3];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const long hw = (long)H * W;
-            const long o = pix[p] - (long)n * hw;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) in[p][k] = A.X[((long)n * 3 + k) * hw + o];
-        }
+    auto stage1_x0 = [&](f4 (&dst)[NT][P]) {          // 3-input Linear + ReLU on the VALU (stage 1 only)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const f4 bias = ldg4(par + kParConv0B * C + 16 * nt + 4 * q);
@@ -458,22 +562,16 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
                 const float w0 = wr[0], w1 = wr[1], w2 = wr[2];
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    x0[nt][p][r] = fmaxf(bias[r] + in[p][0] * w0 + in[p][1] * w1 + in[p][2] * w2, 0.0f);
+                    dst[nt][p][r] = fmaxf(bias[r] + in[p][0] * w0 + in[p][1] * w1 + in[p][2] * w2, 0.0f);
             }
         }
+    };
+    if constexpr (CIN == 3) {
+        stage1_x0(x0);
     } else {
         init_bias(x0, par + kParConv0B * C, q);
         if constexpr (use_ring<C>()) {
-            // B operand staged through the wave's slot first: ordinary global loads issued inside the ring
-            // loop would have to be waited for with vmcnt(0), which drains the LDS-DMA pipeline
-#pragma unroll
-            for (int kk = 0; kk < CIN / 32; ++kk)
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const HL v = load_frag_px(A.X, pix[p], CIN, kk, q);
-                    slot[((kk * P + p) * 2 + 0) * 64 + lane] = v.hi;
-                    slot[((kk * P + p) * 2 + 1) * 64 + lane] = v.lo;
-                }
+            // (the B operand was staged into the wave's slot in the prologue)
             G(I0{}, x0, [&](int kk, int p) {
                 HL o;
                 o.hi = slot[((kk * P + p) * 2 + 0) * 64 + lane];
@@ -488,7 +586,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
 
     {
         f4 h[NT][P];
-        layernorm_plain(x0, h);
+        layernorm_plain<PK>(x0, h);
         store_slot16(slot, h, lane);
     }
     auto from_slot = [&](int kk, int p) {
@@ -500,23 +598,23 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     f4 z[NT][P];
     init_bias(z, par + kParQ1B * C, q);
     G(I1{}, z, from_slot);
-    gelu(z);
+    gelu<PK>(z);
 
     {
         f4 h[NT][P];
-        layernorm_plain(z, h);
+        layernorm_plain<PK>(z, h);
         store_slot16(slot, h, lane);
     }
     f4 ga[NT][P];
     init_bias(ga, par + kParD1B * C, q);
     G(I2{}, ga, from_slot);
-    gelu(ga);
+    gelu<PK>(ga);
     {
         f4 gb[NT][P];
         init_bias(gb, par + kParD1B * C + C, q);
         G(I3{}, gb, from_slot);
-        gelu(gb);
-        layernorm(gb, gb, par + kParGlnG * C, par + kParGlnB * C, q);
+        gelu<PK>(gb);
+        layernorm<PK>(gb, gb, par + kParGlnG * C, par + kParGlnB * C, q);
         lds_barrier();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -539,16 +637,18 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
             // the mixing matrix arrives through the weight ring as chain entry 4 (two units of four 16-token
             // row tiles); this wave needs row tile `wave` of each
             const RingChain c = make_chain<NT>(seq[4], seq[5], seq[6], seq[7], NG - 4);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (BALF_RING_STRICT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // d2 follows: >= 2 units behind
-                chain_issue(c, ring, k + kRingSlots - 1, (gu + k + kRingSlots - 1) & (kRingSlots - 1), wave, lane);
-                const unsigned char *sl = ring + ((gu + k) & (kRingSlots - 1)) * kRingSlotBytes + wave * 2048 + lane * 16;
-                HL &w = k == 0 ? w0 : w1;
+            const int later = c.tot[1] + c.tot[2] + c.tot[3];
+            auto rd = [&](HL &w, int g) {
+                const unsigned char *sl = ring + (g & (kRingSlots - 1)) * kRingSlotBytes + wave * 2048 + lane * 16;
                 w.hi = *reinterpret_cast<const h8 *>(sl);
                 w.lo = *reinterpret_cast<const h8 *>(sl + 1024);
-            }
+            };
+            ring_wait_barrier(1 + later);
+            chain_issue(c, ring, kRingSlots - 1, (gu + kRingSlots - 1) & (kRingSlots - 1), wave, lane);
+            rd(w0, gu);
+            ring_wait_barrier(later);
+            chain_issue(c, ring, kRingSlots, (gu + kRingSlots) & (kRingSlots - 1), wave, lane);
+            rd(w1, gu + 1);
             gu += 2;
         } else {
             const char *wm = reinterpret_cast<const char *>(blob + Br.mix_w) + (wave * 2) * 2048 + lane * 16;
@@ -612,6 +712,8 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
             G(I6{}, x1, from_slot);
             G(I7{}, x1, [&](int kk, int p) { return load_frag_px(A.U, pix[p], C, kk, q); });
         }
+        if constexpr (CIN == 3) stage1_x0(x0);         // recomputed (3 MACs/channel): frees 32 registers across
+                                                       // the whole block branch (bit-identical to the first time)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -619,7 +721,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
                 x1[nt][p] += x0[nt][p];
                 *reinterpret_cast<f4 *>(A.R + pix[p] * C + 16 * nt + 4 * q) = x1[nt][p] + x0[nt][p];
             }
-        layernorm_plain(x1, x1);
+        layernorm_plain<PK>(x1, x1);
         store_slot16(slot, x1, lane);
         f4 m1[NT][P];
         init_bias(m1, par + kParR1B * C + 64, q);
@@ -650,6 +752,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256)
             A.partial[(long)blockIdx.x * C + c] = (red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c]);
+        if (touch == 1.2345678e-30f) A.partial[0] = touch;     // keeps the prologue's u' touches alive
     }
 }
 
