@@ -462,9 +462,10 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     int gu = 0;                                        // global ring unit counter (wave-uniform)
 
     // ---- kernel prologue: put every long-latency request in flight before the first wait ----
-    //  (1) this lane's stage-1 input pixels (NCHW planes), (2) one dword of every u' row the block kernel will
-    //  read much later (pulls the lines into L2), (3) the first three weight units of the ring, (4) the
-    //  per-channel parameters for the LDS cache; only then the barrier that publishes the cache.
+    //  (1) this lane's stage input (NCHW planes at stage 1, fragment rows staged into the slot otherwise),
+    //  (2) the first three weight units of the ring, (3) the per-channel parameters for the LDS cache; only
+    //  then the barrier that publishes the cache.  (Touching the u' rows here to warm L2 for the block
+    //  kernel's later read was tried: FETCH_SIZE doubled for that tensor and the kernel got no faster.)
     float in[P][3];
     if constexpr (CIN == 3) {
 #pragma unroll
@@ -490,13 +491,6 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
                 slot[((kk * P + p) * 2 + 0) * 64 + lane] = xin[kk][p].hi;
                 slot[((kk * P + p) * 2 + 1) * 64 + lane] = xin[kk][p].lo;
             }
-    }
-    float touch = 0.0f;
-    if constexpr (MODE == 1) {
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) touch += A.U[pix[p] * C + 32 * kk + 8 * q];
     }
     if constexpr (use_ring<C>()) {
         const RingChain c0 = make_chain<NT>(seq[0], seq[1], seq[2], seq[3], NG);
@@ -752,7 +746,6 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256)
             A.partial[(long)blockIdx.x * C + c] = (red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c]);
-        if (touch == 1.2345678e-30f) A.partial[0] = touch;     // keeps the prologue's u' touches alive
     }
 }
 

@@ -67,6 +67,28 @@ def kernel_bytes_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
     return per_px * px
 
 
+def measured_traffic(name: str, precision: str, mb: int, hp: int, wp: int):
+    """HBM bytes per launch of `name` from the committed PMC passes (profiles/r1_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this script at 8 images per launch, 1088x1920,
+    gfx950 corrections applied); None when the profile does not cover this shape."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    if not (os.path.isfile(path) and mb == 8 and (hp, wp) == (1088, 1920) and name.startswith("stage")):
+        return None
+    s = int(name[5]) - 1
+    c, cin = [32, 64, 128, 256][s], [3, 32, 64, 128][s]
+    suffix = "16" if precision == "fp16" else ""
+    if "branch" in name:
+        key = f"stage_branch_kernel{suffix}<{c}, {cin}, {0 if 'grid' in name else 1}>"
+    elif "pool" in name:
+        key = f"pool_kernel{suffix}<{c}>"
+    else:
+        return None
+    try:
+        return json.load(open(path))["kernels"][precision][key]["hbm_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
+
+
 def kernel_flops_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
     if name.startswith("stage") and ("grid_branch" in name or "block_branch" in name):
         s = int(name[5]) - 1
@@ -191,7 +213,7 @@ def main():
         gbs = nbytes / (avg_ms * 1e-3) / 1e9 if nbytes else 0.0
         f_m, f_h = tf / peak_tf, gbs / PEAK_HBM_GBS
         roof = {"kernel": name, "avg_launch_ms": avg_ms, "launches": n_launch, "images_per_launch": mb,
-                "traffic": None,
+                "traffic": measured_traffic(name, precision, mb, hp, wp),
                 "mfma": {"achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": f_m,
                          "algorithmic_flop_per_launch": flops},
                 "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h,
