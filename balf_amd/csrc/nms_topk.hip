@@ -108,9 +108,21 @@ __global__ __launch_bounds__(NTHREADS) void nms_tile_kernel(NmsArgs a) {
     const float *img = a.src + (long)b * a.Hs * a.Ws;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < IN_H * IN_W; i += NTHREADS) {
-        const int r = i / IN_W, c = i - r * IN_W;
-        s_in[r * PIN + c] = load_score(a, img, ty0 - LO + r, tx0 - LO + c);
+    {   // tile + halo -> LDS; every load of this thread is issued before the first store (latency paid once)
+        constexpr int NLD = (IN_H * IN_W + NTHREADS - 1) / NTHREADS;
+        float tmp[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * NTHREADS;
+            const int r = i / IN_W, c = i - r * IN_W;
+            tmp[j] = (i < IN_H * IN_W) ? load_score(a, img, ty0 - LO + r, tx0 - LO + c) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * NTHREADS;
+            const int r = i / IN_W, c = i - r * IN_W;
+            if (i < IN_H * IN_W) s_in[r * PIN + c] = tmp[j];
+        }
     }
     __syncthreads();
 
@@ -238,15 +250,24 @@ constexpr int SEL_THREADS = 1024;
 // (1-based) counting from the top (FROM_TOP) or from the bottom; *n_same = how many elements carry
 // exactly that key and *rank_in_same = how many of them are needed to reach `rank`.
 template <bool FROM_TOP, typename KeyFn>
-__device__ unsigned radix_select(int n, int rank, KeyFn key_of, unsigned *s_hist /*[256]*/, int *s_tmp /*[4]*/,
-                                 int *n_same, int *rank_in_same) {
+__device__ unsigned radix_select(int n, int rank, bool cached, const int2 (&ent)[16], const int2 *surv, KeyFn key_of,
+                                 unsigned *s_hist /*[256]*/, int *s_tmp /*[4]*/, int *n_same, int *rank_in_same) {
     unsigned prefix = 0, mask = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int i = threadIdx.x; i < 256; i += SEL_THREADS) s_hist[i] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += SEL_THREADS) {
-            unsigned k;
-            if (key_of(i, &k) && (k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                unsigned k;
+                if (threadIdx.x + j * SEL_THREADS < n && key_of(ent[j], &k) && (k & mask) == prefix)
+                    atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += SEL_THREADS) {
+                unsigned k;
+                if (key_of(surv[i], &k) && (k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -297,17 +318,30 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const int2 *su
     // Selected set = the first K pixels in raster order among those with score >= thr, where thr is the
     // K-th largest score: with ties at thr this can drop a later, higher-scoring pixel -- that is what
     // `argwhere(map >= thr)[:K]` does (test_utils.py:93-95).
+    // survivors of this image, cached in registers when they fit (<= 16 per thread = 16384: a 1080p image has
+    // ~10-20 thousand): the radix passes then never go back to global memory
+    constexpr int CACHE = 16;
+    const bool cached = n <= CACHE * SEL_THREADS;
+    int2 ent[CACHE];
+    if (cached) {
+#pragma unroll
+        for (int j = 0; j < CACHE; ++j) {
+            const int i = threadIdx.x + j * SEL_THREADS;
+            ent[j] = (i < n) ? surv[i] : make_int2(0x7fffffff, 0);      // score bits 0 never reach a threshold > 0
+        }
+    }
+
     unsigned thr = 0;            // score bits; select score >= thr with idx <= idx_cut
     int idx_cut = 0x7fffffff;
     if (n > K) {
         int n_eq, need_eq;
-        thr = radix_select<true>(n, K, [&](int i, unsigned *k) { *k = (unsigned)surv[i].y; return true; },
+        thr = radix_select<true>(n, K, cached, ent, surv, [](int2 e, unsigned *k) { *k = (unsigned)e.y; return true; },
                                  s_hist, s_tmp, &n_eq, &need_eq);
         if (n_eq > need_eq) {    // more than K candidates reach the threshold: keep the raster-first K
             int d0, d1;
+            const unsigned t = thr;
             idx_cut = (int)radix_select<false>(
-                n, K,
-                [&](int i, unsigned *k) { int2 e = surv[i]; *k = (unsigned)e.x; return (unsigned)e.y >= thr; },
+                n, K, cached, ent, surv, [t](int2 e, unsigned *k) { *k = (unsigned)e.x; return (unsigned)e.y >= t; },
                 s_hist, s_tmp, &d0, &d1);
         }
     }
@@ -315,13 +349,19 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const int2 *su
     if (threadIdx.x == 0) *s_cnt = 0;
     for (int i = threadIdx.x; i < npow2; i += SEL_THREADS) keys[i] = ~0ull;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += SEL_THREADS) {
-        const int2 e = surv[i];
+    auto take = [&](int2 e) {
         const unsigned sb = (unsigned)e.y;
         if (sb >= thr && e.x <= idx_cut) {
             const int p = atomicAdd(s_cnt, 1);
             keys[p] = ((unsigned long long)(~sb) << 32) | (unsigned)e.x;   // ascending = score desc, idx asc
         }
+    };
+    if (cached) {
+#pragma unroll
+        for (int j = 0; j < CACHE; ++j)
+            if (threadIdx.x + j * SEL_THREADS < n) take(ent[j]);
+    } else {
+        for (int i = threadIdx.x; i < n; i += SEL_THREADS) take(surv[i]);
     }
     __syncthreads();
     const int cnt = *s_cnt;
