@@ -223,12 +223,39 @@ struct StageArgs {
     const float *blob;
     StageOff off;
     const float *X;       // stage input: NCHW [B,3,H,W] (stage 1) or NHWC [B,H,W,CIN]
+    // stage 1 only: raw uint8 image instead of X (u8_ch = 1 gray [B,sh,sw] or 3 RGB [B,sh,sw,3]; 0 = use X).
+    // Pixel (y, x) of the padded frame reads image pixel (y - u8_top, x - u8_left), zero outside, through the
+    // float32(i / 255.0) table -- make_shape_even + mod_padding_symmetric + /255 of the callers
+    // (/root/reference/balf/utils/test_utils.py:16-32, /root/reference/demo/demo_match.py:22) on the fly.
+    const unsigned char *X8;
+    int u8_ch, u8_h, u8_w, u8_top, u8_left;
     int B, H, W;          // resolution of this stage
     float *U;             // [B,H,W,C] grid-branch output u'
     float *T;             // [B,H,W,C] RCAB body output t
     float *R;             // [B,H,W,C] x1 + x0
     float *partial;       // [B, wgs_per_image, C] channel sums of t
 };
+
+struct InputU8 {           // optional raw-image input of the forward (ch = 0: none)
+    const unsigned char *p;
+    int ch, h, w, top, left;
+};
+
+// stage-1 input of padded-frame pixel (n, y, x): the three network input channels
+__device__ __forceinline__ void load_input3(const StageArgs &A, const float *lut, int n, int y, int x, float (&v)[3]) {
+    if (A.u8_ch == 0) {
+        const long hw = (long)A.H * A.W;
+        const long o = (long)y * A.W + x;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = A.X[((long)n * 3 + k) * hw + o];
+    } else {
+        const int yy = y - A.u8_top, xx = x - A.u8_left;
+        const bool in = yy >= 0 && yy < A.u8_h && xx >= 0 && xx < A.u8_w;
+        const unsigned char *px = A.X8 + (((long)n * A.u8_h + (in ? yy : 0)) * A.u8_w + (in ? xx : 0)) * A.u8_ch;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = in ? lut[px[A.u8_ch == 3 ? k : 0]] : 0.0f;
+    }
+}
 
 template <int C, int P>
 constexpr int stage_lds_bytes() {
@@ -337,9 +364,9 @@ inline Plan make_plan(int B, int Hp, int Wp) {
 
 
 // entry points of the two implementations (detector.hip / detector_f16.hip)
-int forward_f32(const float *blob, const float *x, int B, int Hp, int Wp, float *logits, float *prob, char *ws,
-                const Plan &pl, hipStream_t st);
-int forward_f16(const float *blob, const float *x, int B, int Hp, int Wp, float *logits, float *prob, char *ws,
-                const Plan &pl, hipStream_t st);
+int forward_f32(const float *blob, const float *x, const InputU8 &u8, int B, int Hp, int Wp, float *logits, float *prob,
+                char *ws, const Plan &pl, hipStream_t st);
+int forward_f16(const float *blob, const float *x, const InputU8 &u8, int B, int Hp, int Wp, float *logits, float *prob,
+                char *ws, const Plan &pl, hipStream_t st);
 
 }  // namespace balf

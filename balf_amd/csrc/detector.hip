@@ -122,12 +122,14 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(Stage
     const int iy0 = rem / cols, ix0 = (rem - iy0 * cols) * P;
     const int tok = 16 * wave + li, ty = tok >> 3, tx = tok & 7;
     long pix[P];                                      // flat pixel index (n, y, x) of tile p
+    int py[P], px_[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int y, x;
         if (MODE == 0) { y = ty * (H / 8) + iy0; x = tx * (W / 8) + ix0 + p; }
         else           { y = 8 * iy0 + ty;       x = 8 * (ix0 + p) + tx; }
         pix[p] = ((long)n * H + y) * W + x;
+        py[p] = y; px_[p] = x;
     }
 
     // ---- x0 = relu(conv0(X)) ----
@@ -135,12 +137,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(Stage
     if constexpr (CIN == 3) {
         float in[P][3];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const long hw = (long)H * W;
-            const long o = pix[p] - (long)n * hw;     // y*W + x
-#pragma unroll
-            for (int k = 0; k < 3; ++k) in[p][k] = A.X[((long)n * 3 + k) * hw + o];
-        }
+        for (int p = 0; p < P; ++p) load_input3(A, blob + kLayout.u8_lut, n, py[p], px_[p], in[p]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const f4 bias = ldg4(blob + S.conv0_b + 16 * nt + 4 * q);
@@ -386,11 +383,11 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
 }
 
 template <int C, int CIN>
-int run_stage(const float *blob, int s, const float *X, int B, int H, int W, float *U, float *T, float *R,
+int run_stage(const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
               float *partial, float *chunk, float *scale, hipStream_t st) {
     constexpr int P = StageP<C>::P;
     constexpr int lds = stage_lds_bytes<C, P>();
-    StageArgs a{blob, kLayout.st[s], X, B, H, W, U, T, R, partial};
+    StageArgs a{blob, kLayout.st[s], X, u8.p, u8.ch, u8.h, u8.w, u8.top, u8.left, B, H, W, U, T, R, partial};
     const int per_img = (H / 8) * (W / 8 / P);
     const int nwg = B * per_img;
     auto k0 = stage_branch_kernel<C, CIN, 0>;
@@ -427,8 +424,8 @@ int run_pool(int s, const float *T, const float *R, const float *scale, int B, i
 
 }  // namespace
 
-int forward_f32(const float *blob, const float *x_nchw_dev, int B, int Hp, int Wp, float *logits_dev, float *prob_dev,
-                char *ws, const Plan &pl, hipStream_t st) {
+int forward_f32(const float *blob, const float *x_nchw_dev, const InputU8 &u8, int B, int Hp, int Wp, float *logits_dev,
+                float *prob_dev, char *ws, const Plan &pl, hipStream_t st) {
     float *U = reinterpret_cast<float *>(ws + pl.off_U), *T = reinterpret_cast<float *>(ws + pl.off_T),
           *R = reinterpret_cast<float *>(ws + pl.off_R), *partial = reinterpret_cast<float *>(ws + pl.off_partial),
           *chunk = reinterpret_cast<float *>(ws + pl.off_chunk), *scale = reinterpret_cast<float *>(ws + pl.off_scale);
@@ -438,15 +435,17 @@ int forward_f32(const float *blob, const float *x_nchw_dev, int B, int Hp, int W
 
     for (int b0 = 0; b0 < B; b0 += pl.mb) {
         const int nb = (B - b0 < pl.mb) ? (B - b0) : pl.mb;
-        const float *x = x_nchw_dev + (size_t)b0 * 3 * Hp * Wp;
+        const float *x = x_nchw_dev ? x_nchw_dev + (size_t)b0 * 3 * Hp * Wp : nullptr;
+        InputU8 u8b = u8;
+        if (u8.ch) u8b.p = u8.p + (size_t)b0 * u8.h * u8.w * u8.ch;
         int rc;
-        if ((rc = run_stage<32, 3>(blob, 0, x, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<32, 3>(blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool<32>(0, T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
-        if ((rc = run_stage<64, 32>(blob, 1, X2, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<64, 32>(blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool<64>(1, T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
-        if ((rc = run_stage<128, 64>(blob, 2, X3, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<128, 64>(blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool<128>(2, T, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
-        if ((rc = run_stage<256, 128>(blob, 3, X4, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<256, 128>(blob, 3, X4, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         HeadArgs ha{blob, kLayout.st[3], kLayout.head_w, kLayout.head_b, kLayout.head_alpha, kLayout.head_beta,
                     T, R, scale, nb, h8, w8,
                     logits_dev ? logits_dev + (size_t)b0 * kHeadN * h8 * w8 : nullptr,
@@ -465,10 +464,10 @@ extern "C" size_t balf_forward_workspace_bytes(int B, int Hp, int Wp) {
     return balf::make_plan(B, Hp, Wp).total;
 }
 
-extern "C" int balf_forward(const void *packed_dev, int precision, const float *x_nchw_dev, int B, int Hp, int Wp,
-                            float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
-                            void *stream) {
-    if (!packed_dev || !x_nchw_dev || !prob_dev || !workspace_dev) return BALF_ERR_ARG;
+static int forward_common(const void *packed_dev, int precision, const float *x_nchw_dev, const balf::InputU8 &u8, int B,
+                          int Hp, int Wp, float *logits_dev, float *prob_dev, void *workspace_dev,
+                          size_t workspace_bytes, void *stream) {
+    if (!packed_dev || !prob_dev || !workspace_dev) return BALF_ERR_ARG;
     if (precision != BALF_PREC_FP32 && precision != BALF_PREC_FP16) return BALF_ERR_ARG;
     if (B <= 0 || Hp <= 0 || Wp <= 0) return BALF_ERR_ARG;
     if (Hp % 64 || Wp % 64) return BALF_ERR_SHAPE;
@@ -478,6 +477,26 @@ extern "C" int balf_forward(const void *packed_dev, int precision, const float *
     const float *blob = static_cast<const float *>(packed_dev);
     char *ws = static_cast<char *>(workspace_dev);
     return precision == BALF_PREC_FP32
-               ? balf::forward_f32(blob, x_nchw_dev, B, Hp, Wp, logits_dev, prob_dev, ws, pl, (hipStream_t)stream)
-               : balf::forward_f16(blob, x_nchw_dev, B, Hp, Wp, logits_dev, prob_dev, ws, pl, (hipStream_t)stream);
+               ? balf::forward_f32(blob, x_nchw_dev, u8, B, Hp, Wp, logits_dev, prob_dev, ws, pl, (hipStream_t)stream)
+               : balf::forward_f16(blob, x_nchw_dev, u8, B, Hp, Wp, logits_dev, prob_dev, ws, pl, (hipStream_t)stream);
+}
+
+extern "C" int balf_forward(const void *packed_dev, int precision, const float *x_nchw_dev, int B, int Hp, int Wp,
+                            float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
+                            void *stream) {
+    if (!x_nchw_dev) return BALF_ERR_ARG;
+    return forward_common(packed_dev, precision, x_nchw_dev, balf::InputU8{nullptr, 0, 0, 0, 0, 0}, B, Hp, Wp, logits_dev,
+                          prob_dev, workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int balf_forward_u8(const void *packed_dev, int precision, const unsigned char *image_dev, int channels, int B,
+                               int H, int W, float *logits_dev, float *prob_dev, void *workspace_dev,
+                               size_t workspace_bytes, void *stream) {
+    if (!image_dev || (channels != 1 && channels != 3) || H <= 0 || W <= 0) return BALF_ERR_ARG;
+    // make_shape_even + mod_padding_symmetric(64) (test_utils.py:16-32): padded size and where the image lands
+    const int He = H + (H & 1), We = W + (W & 1);
+    const int Hp = He % 64 ? (He / 64 + 1) * 64 : He, Wp = We % 64 ? (We / 64 + 1) * 64 : We;
+    const balf::InputU8 u8{image_dev, channels, H, W, (Hp - He) / 2, (Wp - We) / 2};
+    return forward_common(packed_dev, precision, nullptr, u8, B, Hp, Wp, logits_dev, prob_dev, workspace_dev,
+                          workspace_bytes, stream);
 }

@@ -429,12 +429,14 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     const int iy0 = rem / cols, ix0 = (rem - iy0 * cols) * P;
     const int tok = 16 * wave + li, ty = tok >> 3, tx = tok & 7;
     long pix[P];
+    int py[P], px_[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         int y, x;
         if (MODE == 0) { y = ty * (H / 8) + iy0; x = tx * (W / 8) + ix0 + p; }
         else           { y = 8 * iy0 + ty;       x = 8 * (ix0 + p) + tx; }
         pix[p] = ((long)n * H + y) * W + x;
+        py[p] = y; px_[p] = x;
     }
 
     // the Linears of this kernel in execution order (the weight ring prefetches across them)
@@ -469,12 +471,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     float in[P][3];
     if constexpr (CIN == 3) {
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const long hw = (long)H * W;
-            const long o = pix[p] - (long)n * hw;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) in[p][k] = A.X[((long)n * 3 + k) * hw + o];
-        }
+        for (int p = 0; p < P; ++p) load_input3(A, blob + kLayout.u8_lut, n, py[p], px_[p], in[p]);
     }
     if constexpr (use_ring<C>() && CIN != 3) {
         // stage input as the first Linear's B operand, staged through the wave's slot: an ordinary global
@@ -853,11 +850,11 @@ __global__ __launch_bounds__(256, 2) void head_kernel16(HeadArgs A) {
 }
 
 template <int C, int CIN>
-int run_stage16(const float *blob, int s, const float *X, int B, int H, int W, float *U, float *T, float *R,
+int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
                 float *partial, float *chunk, float *scale, hipStream_t st) {
     constexpr int P = StageP<C>::P;
     constexpr int lds = stage_lds_bytes16<C, P>();
-    StageArgs a{blob, kLayout.st[s], X, B, H, W, U, T, R, partial};
+    StageArgs a{blob, kLayout.st[s], X, u8.p, u8.ch, u8.h, u8.w, u8.top, u8.left, B, H, W, U, T, R, partial};
     const int per_img = (H / 8) * (W / 8 / P);
     const int nwg = B * per_img;
     auto k0 = stage_branch_kernel16<C, CIN, 0>;
@@ -894,8 +891,8 @@ int run_pool16(int s, const float *T, const float *R, const float *scale, int B,
 
 }  // namespace
 
-int forward_f16(const float *blob, const float *x_nchw_dev, int B, int Hp, int Wp, float *logits_dev, float *prob_dev,
-                char *ws, const Plan &pl, hipStream_t st) {
+int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, int B, int Hp, int Wp, float *logits_dev,
+                float *prob_dev, char *ws, const Plan &pl, hipStream_t st) {
     float *U = reinterpret_cast<float *>(ws + pl.off_U), *T = reinterpret_cast<float *>(ws + pl.off_T),
           *R = reinterpret_cast<float *>(ws + pl.off_R), *partial = reinterpret_cast<float *>(ws + pl.off_partial),
           *chunk = reinterpret_cast<float *>(ws + pl.off_chunk), *scale = reinterpret_cast<float *>(ws + pl.off_scale);
@@ -905,15 +902,17 @@ int forward_f16(const float *blob, const float *x_nchw_dev, int B, int Hp, int W
 
     for (int b0 = 0; b0 < B; b0 += pl.mb) {
         const int nb = (B - b0 < pl.mb) ? (B - b0) : pl.mb;
-        const float *x = x_nchw_dev + (size_t)b0 * 3 * Hp * Wp;
+        const float *x = x_nchw_dev ? x_nchw_dev + (size_t)b0 * 3 * Hp * Wp : nullptr;
+        InputU8 u8b = u8;
+        if (u8.ch) u8b.p = u8.p + (size_t)b0 * u8.h * u8.w * u8.ch;
         int rc;
-        if ((rc = run_stage16<32, 3>(blob, 0, x, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage16<32, 3>(blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool16<32>(0, T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
-        if ((rc = run_stage16<64, 32>(blob, 1, X2, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage16<64, 32>(blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool16<64>(1, T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
-        if ((rc = run_stage16<128, 64>(blob, 2, X3, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage16<128, 64>(blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool16<128>(2, T, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
-        if ((rc = run_stage16<256, 128>(blob, 3, X4, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage16<256, 128>(blob, 3, X4, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         HeadArgs ha{blob, kLayout.st[3], kLayout.head_w, kLayout.head_b, kLayout.head_alpha, kLayout.head_beta,
                     T, R, scale, nb, h8, w8,
                     logits_dev ? logits_dev + (size_t)b0 * kHeadN * h8 * w8 : nullptr,

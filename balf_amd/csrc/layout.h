@@ -46,6 +46,7 @@ struct Layout {
     int head_w;                   // detector_head.dense [80(pad), 256] frags
     int head_b;                   // [80] dense bias
     int head_alpha, head_beta;    // [80] BatchNorm(eval) as z = lin * alpha + beta
+    int u8_lut;                   // [256] float32(i / 255.0): uint8 image -> network input (demo_match.py:22)
     int total;                    // floats
 };
 
@@ -81,6 +82,7 @@ constexpr Layout make_layout() {
     L.head_b = take(kHeadNPad);
     L.head_alpha = take(kHeadNPad);
     L.head_beta = take(kHeadNPad);
+    L.u8_lut = take(256);
     L.total = o;
     return L;
 }

@@ -214,5 +214,6 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
         blob[kLayout.head_alpha + c] = (float)alpha;
         blob[kLayout.head_beta + c] = (float)((double)h[3][c] - (double)h[4][c] * alpha);
     }
+    for (int i = 0; i < 256; ++i) blob[kLayout.u8_lut + i] = (float)((double)i / 255.0);
     return BALF_OK;
 }

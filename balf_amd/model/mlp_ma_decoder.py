@@ -141,3 +141,31 @@ class MLP_MA_DECODER(nn.Module):
                                  logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
                                  ws.numel(), _lib.current_stream_ptr(dev)), "balf_forward")
         return {"logits": logits, "prob": prob}
+
+    def forward_u8(self, images: torch.Tensor, want_logits: bool = True):
+        """Raw uint8 images on the GPU -- gray ``[B,H,W]`` or RGB ``[B,H,W,3]`` -- straight into the network:
+        ``/255``, ``make_shape_even`` and ``mod_padding_symmetric(64)`` (what ``demo_match.detect`` does on the
+        host with NumPy, /root/reference/demo/demo_match.py:21-29) happen inside the first kernels.  Returns the
+        same dict as ``forward`` at the padded size, bit-identical to ``forward`` on the host-prepared input."""
+        if self.training:
+            raise BalfHipError("balf_amd implements the inference path only: call .eval() first")
+        if images.dtype != torch.uint8 or images.dim() not in (3, 4) or (images.dim() == 4 and images.shape[-1] != 3):
+            raise ValueError("expected uint8 [B,H,W] (gray) or [B,H,W,3] (RGB)")
+        if not images.is_cuda:
+            raise BalfHipError("balf_amd has no CPU path: move the model and the input to the GPU")
+        images = images.contiguous()
+        b, h, w = images.shape[:3]
+        ch = 1 if images.dim() == 3 else 3
+        hp, wp, _, _ = arch.padded_hw(h, w)
+        dev = images.device
+        l = lib()
+        blob = self.packed_weights(dev)
+        prob = torch.empty((b, hp, wp), dtype=torch.float32, device=dev)
+        logits = torch.empty((b, 65, hp // 8, wp // 8), dtype=torch.float32, device=dev) if want_logits else None
+        nbytes = l.balf_forward_workspace_bytes(b, hp, wp)
+        ws = ops._workspace("forward", dev, nbytes)
+        with torch.cuda.device(dev):
+            check(l.balf_forward_u8(blob.data_ptr(), self._precision_code(), images.data_ptr(), ch, b, h, w,
+                                    logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), _lib.current_stream_ptr(dev)), "balf_forward_u8")
+        return {"logits": logits, "prob": prob}

@@ -36,6 +36,17 @@ def detect_batch(model, x_pad: torch.Tensor, h: int, w: int, border: int = 15, n
     return idx, score, count, prob
 
 
+def detect_batch_u8(model, images_u8: torch.Tensor, border: int = 15, nms_size: int = 15, num_points: int = 1000):
+    """Raw uint8 images on the GPU (gray ``[B,H,W]`` or RGB ``[B,H,W,3]``) -> keypoints, nothing on the host:
+    normalisation and padding are fused into the first kernels (``MLP_MA_DECODER.forward_u8``), crop/border/NMS/
+    top-K into the last.  Same return values as :func:`detect_batch`."""
+    h, w = images_u8.shape[1], images_u8.shape[2]
+    _, _, top, left = arch.padded_hw(h, w)
+    prob = model.forward_u8(images_u8, want_logits=False)["prob"]
+    idx, score, count = ops.nms_topk(prob, top, left, h, w, border, nms_size, num_points)
+    return idx, score, count, prob
+
+
 def pad_batch(images_rgb_norm: np.ndarray) -> torch.Tensor:
     """[B,H,W,3] float in [0,1] -> padded [B,3,Hp,Wp] float32 CPU tensor (make_shape_even +
     mod_padding_symmetric, test_utils.py:16-32; torch.tensor(...).permute, train_utils.py:426-428)."""

@@ -76,6 +76,16 @@ int balf_forward(const void *packed_dev, int precision, const float *x_nchw_dev,
                  float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
                  void *stream);
 
+/* Same forward, fed with the raw uint8 image(s): gray [B,H,W] (channels = 1, replicated to the three input
+ * channels) or RGB [B,H,W,3] (channels = 3).  The /255, make_shape_even and mod_padding_symmetric(64) of the
+ * callers (demo/demo_match.py:22-29, balf/utils/test_utils.py:16-32) happen inside the first kernels; the
+ * outputs have the PADDED size: Hp = H rounded up to even then to a multiple of 64 (same for W), the image at
+ * rows (Hp-He)/2.., i.e. prob_dev [B,Hp,Wp], logits_dev [B,65,Hp/8,Wp/8], workspace for (B,Hp,Wp).  Results
+ * are bit-identical to balf_forward on the host-prepared float input. */
+int balf_forward_u8(const void *packed_dev, int precision, const unsigned char *image_dev, int channels, int B,
+                    int H, int W, float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
+                    void *stream);
+
 /* ---- window-max NMS, dense form (apply_nms) ------------------------------------------------
  * score_dev [B,H,W] fp32 -> out_dev [B,H,W] fp32 = rb * (rb == max over the clipped
  * nms_size x nms_size window), rb = score with a `border`-pixel frame zeroed. */

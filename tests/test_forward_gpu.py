@@ -164,6 +164,28 @@ def test_prob_is_a_distribution_at_full_size(model):
     assert torch.allclose(cell + dust, torch.ones_like(cell), atol=1e-5)
 
 
+@pytest.mark.parametrize("hw", [(100, 130), (481, 641), (480, 640)])
+@pytest.mark.parametrize("rgb", [False, True])
+def test_uint8_input_is_bit_identical_to_host_preprocessing(model, model16, hw, rgb):
+    """/255 + make_shape_even + mod_padding_symmetric fused into the first kernels."""
+    from balf_amd import pipeline
+    h, w = hw
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, size=(2, h, w, 3) if rgb else (2, h, w), dtype=np.uint8)
+    rgb_norm = (img if rgb else np.repeat(img[..., None], 3, axis=-1)).astype(np.float64) / 255.0   # demo_match.py:22
+    x = pipeline.pad_batch(rgb_norm).to("cuda:0")
+    t = torch.from_numpy(img).to("cuda:0")
+    for m in (model, model16):
+        with torch.inference_mode():
+            a = m(x)
+            b = m.forward_u8(t)
+        assert a["prob"].shape == b["prob"].shape
+        assert torch.equal(a["prob"], b["prob"]) and torch.equal(a["logits"], b["logits"])
+    i1, s1, c1, _ = pipeline.detect_batch(model16, x, h, w, 15, 15, 300)
+    i2, s2, c2, _ = pipeline.detect_batch_u8(model16, t, 15, 15, 300)
+    assert torch.equal(i1, i2) and torch.equal(s1, s2) and torch.equal(c1, c2)
+
+
 def test_error_behaviour(model):
     from balf_amd._lib import BalfHipError
     with pytest.raises(ValueError):
