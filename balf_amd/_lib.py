@@ -33,6 +33,9 @@ PROTOTYPES = {
     "balf_window_nms": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp]),
     "balf_nms_topk_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "balf_nms_topk": (_i, [_fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _fp, _vp, _vp, _sz, _vp]),
+    "balf_greedy_nms_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "balf_greedy_nms": (_i, [_fp, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _vp, _fp, _fp, _vp, _vp, _vp,
+                            _sz, _vp]),
     "balf_profile_num_slots": (_i, []),
     "balf_profile_slot_name": (C.c_char_p, [_i]),
     "balf_profile_begin": (_i, []),

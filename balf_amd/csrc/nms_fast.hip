@@ -1,0 +1,240 @@
+// Greedy "SuperPoint" NMS of the demo path on gfx950.
+//
+// Replaces get_points_direct_from_score_map + nms_fast (+ soft_argmax_points)
+// (/root/reference/balf/utils/test_utils.py:97-215, called from /root/reference/demo/demo_match.py:45-57):
+// every pixel with score >= conf_thresh is a candidate; candidates are visited in descending score order and
+// one is kept iff no already-kept candidate lies within Chebyshev distance dist_thresh (a (2d+1)^2 window).
+//
+// The sequential sweep has an exact parallel form (greedy maximal independent set with fixed priorities):
+// repeat { every ALIVE candidate that is the maximum of the alive candidates in its window is KEPT;
+//          every alive candidate with a newly kept one in its window dies } until nobody is alive.
+// Priority = (score, then raster-first) packed into one 64-bit key, so the result is deterministic; the
+// reference's order among exactly equal scores is whatever NumPy's unstable argsort produces.
+//
+// Kernels: greedy_init (crop + border + threshold -> key map), greedy_keep (LDS-tiled separable window max of
+// the 64-bit keys), greedy_kill (window OR of the newly-kept flags, alive count), greedy_collect (kept pixels ->
+// survivor list), then the top-K / sort kernel of nms_topk.hip and the optional sub-pixel soft-argmax.
+#include "common.h"
+#include "prof.h"
+
+int balf_topk_select_launch(const int2 *surv, const int *counts, long cap, int B, int K, int zero_fallback,
+                            int32_t *idx_dev, float *score_dev, int32_t *count_dev, hipStream_t st);
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr int GT = 32;            // tile side
+constexpr int GD_MAX = 16;        // max dist_thresh
+constexpr int GTHREADS = 256;
+
+struct GreedyArgs {
+    const float *src;             // [B, Hs, Ws]
+    int Hs, Ws, crop_y, crop_x, H, W, border;
+    float conf;
+    int d;                        // dist_thresh
+    u64 *key;                     // [B, H, W]  (score bits << 32 | ~idx) while alive, 0 otherwise
+    unsigned char *newk;          // [B, H, W]  kept in the current round
+    unsigned char *kept;          // [B, H, W]
+    int *alive;                   // [1] alive candidates left (written by the last round of a group)
+    int count_alive;
+};
+
+__device__ __forceinline__ float g_score(const GreedyArgs &a, const float *img, int y, int x) {
+    if (y < a.border || y >= a.H - a.border || x < a.border || x >= a.W - a.border) return 0.0f;
+    return img[(long)(a.crop_y + y) * a.Ws + (a.crop_x + x)];
+}
+
+__global__ __launch_bounds__(GTHREADS) void greedy_init_kernel(GreedyArgs a) {
+    const long hw = (long)a.H * a.W;
+    const int b = blockIdx.y;
+    const float *img = a.src + (long)b * a.Hs * a.Ws;
+    for (long i = (long)blockIdx.x * GTHREADS + threadIdx.x; i < hw; i += (long)gridDim.x * GTHREADS) {
+        const int y = (int)(i / a.W), x = (int)(i - (long)y * a.W);
+        const float v = g_score(a, img, y, x);
+        a.key[b * hw + i] = (v >= a.conf) ? (((u64)__float_as_uint(v) << 32) | (u64)(0xffffffffu - (unsigned)i)) : 0ull;
+        a.kept[b * hw + i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(GTHREADS) void greedy_keep_kernel(GreedyArgs a) {
+    constexpr int S = GT + 2 * GD_MAX;
+    __shared__ u64 s_in[S * (S + 1)];
+    __shared__ u64 s_row[S * GT];
+    const int d = a.d, side = GT + 2 * d;
+    const int b = blockIdx.z, ty0 = blockIdx.y * GT, tx0 = blockIdx.x * GT;
+    const long hw = (long)a.H * a.W;
+    const u64 *key = a.key + b * hw;
+    for (int i = threadIdx.x; i < side * side; i += GTHREADS) {
+        const int r = i / side, c = i - r * side;
+        const int y = ty0 - d + r, x = tx0 - d + c;
+        s_in[r * (S + 1) + c] = (y >= 0 && y < a.H && x >= 0 && x < a.W) ? key[(long)y * a.W + x] : 0ull;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < side * GT; i += GTHREADS) {          // row pass
+        const int r = i / GT, c = i - r * GT;
+        u64 m = s_in[r * (S + 1) + c];
+        for (int k = 1; k <= 2 * d; ++k) { const u64 v = s_in[r * (S + 1) + c + k]; m = v > m ? v : m; }
+        s_row[r * GT + c] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < GT * GT; i += GTHREADS) {            // column pass + decision
+        const int r = i / GT, c = i - r * GT;
+        const int y = ty0 + r, x = tx0 + c;
+        if (y >= a.H || x >= a.W) continue;
+        u64 m = s_row[r * GT + c];
+        for (int k = 1; k <= 2 * d; ++k) { const u64 v = s_row[(r + k) * GT + c]; m = v > m ? v : m; }
+        const u64 own = s_in[(r + d) * (S + 1) + c + d];
+        a.newk[b * hw + (long)y * a.W + x] = (own != 0ull && own == m) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(GTHREADS) void greedy_kill_kernel(GreedyArgs a) {
+    constexpr int S = GT + 2 * GD_MAX;
+    __shared__ unsigned char s_in[S * (S + 4)];
+    __shared__ unsigned char s_row[S * GT];
+    __shared__ int s_cnt;
+    const int d = a.d, side = GT + 2 * d;
+    const int b = blockIdx.z, ty0 = blockIdx.y * GT, tx0 = blockIdx.x * GT;
+    const long hw = (long)a.H * a.W;
+    const unsigned char *nk = a.newk + b * hw;
+    if (threadIdx.x == 0) s_cnt = 0;
+    for (int i = threadIdx.x; i < side * side; i += GTHREADS) {
+        const int r = i / side, c = i - r * side;
+        const int y = ty0 - d + r, x = tx0 - d + c;
+        s_in[r * (S + 4) + c] = (y >= 0 && y < a.H && x >= 0 && x < a.W) ? nk[(long)y * a.W + x] : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < side * GT; i += GTHREADS) {
+        const int r = i / GT, c = i - r * GT;
+        unsigned char m = 0;
+        for (int k = 0; k <= 2 * d; ++k) m |= s_in[r * (S + 4) + c + k];
+        s_row[r * GT + c] = m;
+    }
+    __syncthreads();
+    int alive = 0;
+    for (int i = threadIdx.x; i < GT * GT; i += GTHREADS) {
+        const int r = i / GT, c = i - r * GT;
+        const int y = ty0 + r, x = tx0 + c;
+        if (y >= a.H || x >= a.W) continue;
+        unsigned char m = 0;
+        for (int k = 0; k <= 2 * d; ++k) m |= s_row[(r + k) * GT + c];
+        const long p = b * hw + (long)y * a.W + x;
+        if (s_in[(r + d) * (S + 4) + c + d]) a.kept[p] = 1;
+        if (a.key[p] != 0ull) {
+            if (m) a.key[p] = 0ull;            // newly kept itself, or suppressed by a newly kept neighbour
+            else ++alive;
+        }
+    }
+    if (a.count_alive) {
+        if (alive) atomicAdd(&s_cnt, alive);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) atomicAdd(a.alive, s_cnt);
+    }
+}
+
+__global__ __launch_bounds__(GTHREADS) void greedy_collect_kernel(GreedyArgs a, int2 *surv, int *counts, long cap) {
+    const long hw = (long)a.H * a.W;
+    const int b = blockIdx.y;
+    const float *img = a.src + (long)b * a.Hs * a.Ws;
+    for (long i = (long)blockIdx.x * GTHREADS + threadIdx.x; i < hw; i += (long)gridDim.x * GTHREADS) {
+        if (a.kept[b * hw + i]) {
+            const int y = (int)(i / a.W), x = (int)(i - (long)y * a.W);
+            const int pos = atomicAdd(&counts[b], 1);
+            surv[b * cap + pos] = make_int2((int)i, __float_as_int(g_score(a, img, y, x)));
+        }
+    }
+}
+
+// soft_argmax_points (test_utils.py:170-215) on the selected points: the patch is normalised by its sum + 1e-6,
+// log-ed and soft-max-ed, which is the patch itself re-normalised; the expected (x, y) inside the patch replaces
+// the integer position: p += E[pos] - patch//2.  (torchgeometry's SpatialSoftArgmax2d is not installed in the
+// build container, so this follows its documented definition: "parity unpinned".)
+__global__ void subpixel_kernel(GreedyArgs a, const int32_t *idx, const int32_t *count, int K, int patch, float *xy) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = count[b] < K ? count[b] : K;
+    if (i >= K) return;
+    float *o = xy + ((long)b * K + i) * 2;
+    if (i >= n) { o[0] = 0.0f; o[1] = 0.0f; return; }
+    const float *img = a.src + (long)b * a.Hs * a.Ws;
+    const int p = idx[(long)b * K + i];
+    const int y = p / a.W, x = p - y * a.W;
+    const int pad = patch / 2;
+    float s = 0.0f, sx = 0.0f, sy = 0.0f;
+    for (int dy = 0; dy < patch; ++dy)
+        for (int dx = 0; dx < patch; ++dx) {
+            const int yy = y - pad + dy, xx = x - pad + dx;
+            const float v = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? g_score(a, img, yy, xx) : 0.0f;
+            s += v; sx += v * dx; sy += v * dy;
+        }
+    o[0] = (float)x + sx / s - (float)pad;
+    o[1] = (float)y + sy / s - (float)pad;
+}
+
+}  // namespace
+
+extern "C" size_t balf_greedy_nms_workspace_bytes(int B, int H, int W, int K) {
+    if (B <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
+    const size_t px = (size_t)B * H * W;
+    return balf_align_up(px * 8, 256) + 2 * balf_align_up(px, 256) + 256 /*alive*/ +
+           balf_align_up((size_t)B * sizeof(int), 256) + px * sizeof(int2);
+}
+
+extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W,
+                               int border, float conf_thresh, int dist_thresh, int K, int subpixel_patch,
+                               int32_t *idx_dev, float *score_dev, float *xy_dev, int32_t *count_dev,
+                               int32_t *total_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    if (!prob_dev || !idx_dev || !score_dev || !count_dev || !workspace_dev) return BALF_ERR_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || K <= 0 || K > BALF_MAX_TOPK || border < 0) return BALF_ERR_ARG;
+    if (!(conf_thresh > 0.0f) || dist_thresh < 0 || dist_thresh > GD_MAX) return BALF_ERR_ARG;
+    if (subpixel_patch < 0 || subpixel_patch > 16 || (subpixel_patch > 0 && !xy_dev)) return BALF_ERR_ARG;
+    if (crop_y < 0 || crop_x < 0 || crop_y + H > Hp || crop_x + W > Wp) return BALF_ERR_SHAPE;
+    if ((long)H * W > 0x7fffffffL) return BALF_ERR_SHAPE;
+    if (workspace_bytes < balf_greedy_nms_workspace_bytes(B, H, W, K)) return BALF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t px = (size_t)B * H * W;
+    char *w = static_cast<char *>(workspace_dev);
+    u64 *key = reinterpret_cast<u64 *>(w); w += balf_align_up(px * 8, 256);
+    unsigned char *newk = reinterpret_cast<unsigned char *>(w); w += balf_align_up(px, 256);
+    unsigned char *kept = reinterpret_cast<unsigned char *>(w); w += balf_align_up(px, 256);
+    int *alive = reinterpret_cast<int *>(w); w += 256;
+    int *counts = reinterpret_cast<int *>(w); w += balf_align_up((size_t)B * sizeof(int), 256);
+    int2 *surv = reinterpret_cast<int2 *>(w);
+
+    GreedyArgs a{prob_dev, Hp, Wp, crop_y, crop_x, H, W, border, conf_thresh, dist_thresh, key, newk, kept, alive, 0};
+    const dim3 lin((unsigned)balf_ceil_div((long)H * W, GTHREADS * 4), B), tiles(balf_ceil_div(W, GT), balf_ceil_div(H, GT), B);
+    hipLaunchKernelGGL(greedy_init_kernel, lin, dim3(GTHREADS), 0, st, a);
+    BALF_LAUNCH_CHECK();
+    // rounds in groups of 4; the last kill of a group counts the candidates still alive, read back with ONE
+    // stream synchronisation per group (the only entry point of the library that synchronises)
+    for (int round = 0;; round += 4) {
+        if (round > 4096) return BALF_ERR_LAUNCH;      // cannot happen: every round keeps >= 1 per alive region
+        if (hipMemsetAsync(alive, 0, sizeof(int), st) != hipSuccess) return BALF_ERR_LAUNCH;
+        for (int r = 0; r < 4; ++r) {
+            a.count_alive = (r == 3);
+            hipLaunchKernelGGL(greedy_keep_kernel, tiles, dim3(GTHREADS), 0, st, a);
+            hipLaunchKernelGGL(greedy_kill_kernel, tiles, dim3(GTHREADS), 0, st, a);
+        }
+        BALF_LAUNCH_CHECK();
+        int h_alive = 0;
+        if (hipMemcpyAsync(&h_alive, alive, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return BALF_ERR_LAUNCH;
+        if (h_alive == 0) break;
+    }
+    if (hipMemsetAsync(counts, 0, balf_align_up((size_t)B * sizeof(int), 256), st) != hipSuccess) return BALF_ERR_LAUNCH;
+    hipLaunchKernelGGL(greedy_collect_kernel, lin, dim3(GTHREADS), 0, st, a, surv, counts, (long)H * W);
+    BALF_LAUNCH_CHECK();
+    if (total_dev && hipMemcpyAsync(total_dev, counts, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return BALF_ERR_LAUNCH;
+    // the K best kept points by score, sorted (score desc, index asc); count_dev = rows returned (<= K)
+    int rc = balf_topk_select_launch(surv, counts, (long)H * W, B, K, /*zero_fallback=*/0, idx_dev, score_dev,
+                                     count_dev, st);
+    if (rc != BALF_OK) return rc;
+    if (subpixel_patch > 0) {
+        hipLaunchKernelGGL(subpixel_kernel, dim3(balf_ceil_div(K, 256), B), dim3(256), 0, st, a, idx_dev, count_dev, K,
+                           subpixel_patch, xy_dev);
+        BALF_LAUNCH_CHECK();
+    }
+    return BALF_OK;
+}

@@ -293,8 +293,9 @@ __device__ unsigned radix_select(int n, int rank, bool cached, const int2 (&ent)
 }
 
 __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const int2 *surv_all, const int *surv_count,
-                                                                  long cap, int K, int npow2, int32_t *idx_out,
-                                                                  float *score_out, int32_t *count_out) {
+                                                                  long cap, int K, int npow2, int zero_fallback,
+                                                                  int32_t *idx_out, float *score_out,
+                                                                  int32_t *count_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);       // [npow2]
     unsigned *s_hist = reinterpret_cast<unsigned *>(keys + npow2);                 // [256]
@@ -307,6 +308,11 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const int2 *su
     int32_t *idx_o = idx_out + (long)b * K;
     float *sc_o = score_out + (long)b * K;
 
+    if (n == 0 && !zero_fallback) {                       // greedy-NMS caller: no candidates, no points
+        for (int i = threadIdx.x; i < K; i += SEL_THREADS) { idx_o[i] = -1; sc_o[i] = 0.0f; }
+        if (threadIdx.x == 0) count_out[b] = 0;
+        return;
+    }
     if (n == 0) {
         // No positive NMS score: the reference's threshold falls back to 0.0 and `map >= 0` holds
         // everywhere, so it returns the first K pixels in raster order (test_utils.py:84-95).
@@ -414,6 +420,22 @@ int next_pow2(int v) {
 
 }  // namespace
 
+// shared by balf_nms_topk and balf_greedy_nms (nms_fast.hip)
+int balf_topk_select_launch(const int2 *surv, const int *counts, long cap, int B, int K, int zero_fallback,
+                            int32_t *idx_dev, float *score_dev, int32_t *count_dev, hipStream_t st) {
+    const int npow2 = next_pow2(K);
+    const size_t smem = (size_t)npow2 * 8 + 256 * 4 + 8 * 4;
+    if (smem > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_select_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return BALF_ERR_LAUNCH;
+    BALF_PROF(balf_prof::kTopkSelect, st,
+              hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(SEL_THREADS), smem, st, surv, counts, cap, K, npow2,
+                                 zero_fallback, idx_dev, score_dev, count_dev));
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}
+
 extern "C" int balf_window_nms(const float *score_dev, int B, int H, int W, int border, int nms_size,
                                float *out_dev, void *stream) {
     if (!score_dev || !out_dev || B <= 0 || H <= 0 || W <= 0 || border < 0) return BALF_ERR_ARG;
@@ -450,15 +472,7 @@ extern "C" int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int c
     int rc = launch_nms_tiles(a, B, st);
     if (rc != BALF_OK) return rc;
 
-    const int npow2 = next_pow2(K);
-    const size_t smem = (size_t)npow2 * 8 + 256 * 4 + 8 * 4;
-    if (smem > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_select_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-        return BALF_ERR_LAUNCH;
-    BALF_PROF(balf_prof::kTopkSelect, st,
-              hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(SEL_THREADS), smem, st, surv, counts, (long)H * W,
-                                 K, npow2, idx_dev, score_dev, count_dev));
-    BALF_LAUNCH_CHECK();
+    rc = balf_topk_select_launch(surv, counts, (long)H * W, B, K, /*zero_fallback=*/1, idx_dev, score_dev, count_dev, st);
+    if (rc != BALF_OK) return rc;
     return BALF_OK;
 }

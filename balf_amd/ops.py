@@ -66,6 +66,30 @@ def nms_topk(prob: torch.Tensor, crop_y: int, crop_x: int, h: int, w: int, borde
     return idx, score, count
 
 
+def greedy_nms(prob: torch.Tensor, crop_y: int, crop_x: int, h: int, w: int, border: int, conf_thresh: float,
+               dist_thresh: int, k: int, subpixel_patch: int = 0):
+    """Greedy NMS of the demo path (balf_greedy_nms in include/balf_hip.h).  Returns
+    (idx [B,K] int32, score [B,K], xy [B,K,2] or None, count [B], total [B])."""
+    require_gpu_tensor(prob, "prob")
+    if prob.dtype != torch.float32 or prob.dim() != 3:
+        raise BalfHipError("prob must be a [B,Hp,Wp] float32 tensor")
+    b, hp, wp = prob.shape
+    dev = prob.device
+    idx = torch.empty((b, k), dtype=torch.int32, device=dev)
+    score = torch.empty((b, k), dtype=torch.float32, device=dev)
+    xy = torch.empty((b, k, 2), dtype=torch.float32, device=dev) if subpixel_patch > 0 else None
+    count = torch.empty((b,), dtype=torch.int32, device=dev)
+    total = torch.empty((b,), dtype=torch.int32, device=dev)
+    ws = _workspace("greedy", dev, lib().balf_greedy_nms_workspace_bytes(b, h, w, k))
+    with torch.cuda.device(dev):
+        check(lib().balf_greedy_nms(prob.data_ptr(), b, hp, wp, int(crop_y), int(crop_x), int(h), int(w), int(border),
+                                    float(conf_thresh), int(dist_thresh), int(k), int(subpixel_patch), idx.data_ptr(),
+                                    score.data_ptr(), xy.data_ptr() if xy is not None else None, count.data_ptr(),
+                                    total.data_ptr(), ws.data_ptr(), ws.numel(), current_stream_ptr(dev)),
+              "balf_greedy_nms")
+    return idx, score, xy, count, total
+
+
 def profile_begin() -> None:
     check(lib().balf_profile_begin(), "balf_profile_begin")
 

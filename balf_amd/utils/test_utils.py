@@ -88,3 +88,38 @@ def get_point_coordinates(map, scale_value=1., num_points=1000, threshold=-1, or
         raise ValueError(order_coord)
     out[:, 2], out[:, 3] = scale_value, sc
     return out
+
+
+def get_points_direct_from_score_map(heatmap, conf_thresh=0.015, nms_size=15, subpixel=True, patch_size=5,
+                                     scale_value=1., order_coord='xysr'):
+    """Mirror of the demo's post-processing (/root/reference/balf/utils/test_utils.py:97-128): confidence
+    threshold, greedy ``nms_fast`` with a (2*nms_size+1)^2 suppression window, sort by confidence, optional
+    sub-pixel soft-argmax -> rows ``[x, y, scale, score]`` float64 (``np.zeros((0, 4))`` when nothing passes).
+    Among exactly equal scores the raster-first point wins (the reference's order there is NumPy's unstable
+    argsort).  The sub-pixel step follows torchgeometry's documented soft-argmax (parity unpinned)."""
+    m = _as_map(heatmap)
+    h, w = m.shape
+    t = torch.from_numpy(m).to(_device()).unsqueeze(0)
+    k = min(ops._lib.MAX_TOPK, h * w)
+    idx, score, xy, count, total = ops.greedy_nms(t, 0, 0, h, w, 0, float(conf_thresh), int(nms_size), k,
+                                                  int(patch_size) if subpixel else 0)
+    n = int(count[0])
+    if int(total[0]) > n:
+        raise NotImplementedError(f"{int(total[0])} points survive the NMS, more than the {k} the kernel returns")
+    if n == 0:
+        return np.zeros((0, 4))
+    i = idx[0, :n].cpu().numpy().astype(np.int64)
+    out = np.empty((n, 4), dtype=np.float64)
+    if subpixel:
+        p = xy[0, :n].cpu().numpy().astype(np.float64)
+        xs, ys = p[:, 0], p[:, 1]
+    else:
+        xs, ys = (i % w).astype(np.float64), (i // w).astype(np.float64)
+    if order_coord == 'xysr':
+        out[:, 0], out[:, 1] = xs, ys
+    elif order_coord == 'yxsr':
+        out[:, 0], out[:, 1] = ys, xs
+    else:
+        raise ValueError(order_coord)
+    out[:, 2], out[:, 3] = scale_value, score[0, :n].cpu().numpy()
+    return out

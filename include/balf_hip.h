@@ -104,6 +104,21 @@ int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int 
                   int border, int nms_size, int K, int32_t *idx_dev, float *score_dev,
                   int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* ---- greedy "SuperPoint" NMS of the demo path --------------------------------------
+ * Replaces get_points_direct_from_score_map + nms_fast (+ soft_argmax_points), balf/utils/test_utils.py:97-215,
+ * as called by demo/demo_match.py:45-57.  The score map of image b is prob[b, crop_y:+H, crop_x:+W] with a
+ * `border` frame zeroed; candidates = pixels >= conf_thresh (> 0); a candidate is kept iff no higher-scoring kept
+ * candidate lies within Chebyshev distance dist_thresh (<= 16).  Output rows sorted by score descending (flat
+ * index ascending among equal scores): idx_dev[B,K] (-1 padded), score_dev[B,K], count_dev[B] = rows returned
+ * (<= K), total_dev[B] = points kept before truncation (may be NULL).  subpixel_patch > 0 additionally writes
+ * xy_dev[B,K,2] = (x, y) refined by the patch soft-argmax.  NOTE: the number of suppression rounds is data
+ * dependent, so this entry point calls hipStreamSynchronize(stream) once per group of 4 rounds. */
+size_t balf_greedy_nms_workspace_bytes(int B, int H, int W, int K);
+int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W, int border,
+                    float conf_thresh, int dist_thresh, int K, int subpixel_patch, int32_t *idx_dev,
+                    float *score_dev, float *xy_dev, int32_t *count_dev, int32_t *total_dev, void *workspace_dev,
+                    size_t workspace_bytes, void *stream);
+
 /* ---- measurement aid (not part of the data path) ---------------------------------------------
  * Between balf_profile_begin() and balf_profile_end() every kernel launch of the library is bracketed
  * by a hipEvent pair on its launch stream.  balf_profile_end() waits for those events and returns,

@@ -217,3 +217,46 @@ def extract_detections(sd, image_rgb_norm: np.ndarray, nms_size=15, num_points=2
         prob = detector_forward(sd, x)["prob"][0].numpy()
     idx, sc = detect_from_prob(prob, h, w, border_size, nms_size, num_points)
     return points_xysr(idx, sc, w), prob
+
+
+# ----------------------------------------------------------------------------------------
+# demo post-processing: greedy nms_fast (+ sub-pixel) -- SURVEY 8f row f1
+# ----------------------------------------------------------------------------------------
+def greedy_nms(heatmap: np.ndarray, conf_thresh: float, dist_thresh: int) -> Tuple[np.ndarray, np.ndarray]:
+    """``get_points_direct_from_score_map(subpixel=False)`` (test_utils.py:97-168): candidates >= conf_thresh are
+    visited in descending score order (raster-first among equal scores); one is kept iff no kept candidate lies
+    within Chebyshev distance ``dist_thresh``.  Returns (flat idx, score) sorted by score descending."""
+    h, w = heatmap.shape
+    ys, xs = np.where(heatmap >= conf_thresh)
+    if xs.size == 0:
+        return np.zeros(0, np.int64), np.zeros(0, heatmap.dtype)
+    sc = heatmap[ys, xs]
+    order = np.lexsort((ys * w + xs, -sc.astype(np.float64)))
+    blocked = np.zeros((h + 2 * dist_thresh, w + 2 * dist_thresh), bool)
+    cand = np.zeros_like(blocked)
+    cand[ys + dist_thresh, xs + dist_thresh] = True
+    keep = []
+    for j in order:
+        y, x = ys[j] + dist_thresh, xs[j] + dist_thresh
+        if cand[y, x] and not blocked[y, x]:
+            keep.append(j)
+            blocked[y - dist_thresh:y + dist_thresh + 1, x - dist_thresh:x + dist_thresh + 1] = True
+    keep = np.asarray(keep, np.int64)
+    return (ys[keep] * w + xs[keep]).astype(np.int64), sc[keep]
+
+
+def soft_argmax_refine(heatmap: np.ndarray, idx: np.ndarray, patch: int) -> np.ndarray:
+    """``soft_argmax_points`` (test_utils.py:170-215) by its definition: the patch, normalised by its sum + 1e-6,
+    log-ed and soft-max-ed (= the patch re-normalised), gives the expected (x, y); p += E - patch//2.
+    PARITY UNPINNED: torchgeometry (SpatialSoftArgmax2d) is not installed in the build container."""
+    h, w = heatmap.shape
+    pad = patch // 2
+    hp = np.pad(heatmap.astype(np.float64), pad, mode="constant")
+    out = np.zeros((idx.size, 2))
+    for n, p in enumerate(idx):
+        y, x = int(p) // w, int(p) % w
+        pt = hp[y:y + patch, x:x + patch]
+        s = pt.sum()
+        gx, gy = np.meshgrid(np.arange(patch), np.arange(patch))
+        out[n] = (x + (pt * gx).sum() / s - pad, y + (pt * gy).sum() / s - pad)
+    return out

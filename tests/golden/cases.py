@@ -73,7 +73,23 @@ def nms_input(spec):
         up = np.kron(g, np.ones((4, 4), np.float32))[:h, :w]
         noise = rng.random((h, w), dtype=np.float32) * 0.05
         return (np.exp(4.0 * up + noise) / np.exp(4.05) * 0.3).astype(np.float32)
+    if kind == "ramp":       # strictly increasing along x: a long dependency chain for the greedy order
+        return (np.arange(w, dtype=np.float32)[None, :] * 0.004 + np.arange(h, dtype=np.float32)[:, None] * 1e-5
+                + 0.01).astype(np.float32)
     raise ValueError(kind)
 
 
 PAD_SIZES = [(480, 640), (720, 1280), (1080, 1920), (481, 641), (64, 64), (100, 130), (511, 512), (65, 1)]
+
+
+# Greedy SuperPoint NMS (nms_fast) cases: get_points_direct_from_score_map(subpixel=False)
+GREEDY_CASES = {
+    "g_rand_96x128":   dict(h=96, w=128, seed=21, kind="rand", border=15, conf=0.5, nms=15),
+    "g_rand_dense":    dict(h=120, w=160, seed=22, kind="rand", border=15, conf=0.001, nms=15),
+    "g_blobs_240x320": dict(h=240, w=320, seed=23, kind="blobs", border=15, conf=0.001, nms=15),
+    "g_small_radius":  dict(h=100, w=90, seed=24, kind="rand", border=4, conf=0.2, nms=3),
+    "g_sparse":        dict(h=150, w=170, seed=6, kind="sparse", border=15, conf=0.015, nms=15),
+    "g_none":          dict(h=64, w=64, seed=25, kind="zeros", border=15, conf=0.001, nms=15),
+    "g_ramp":          dict(h=80, w=200, seed=26, kind="ramp", border=0, conf=0.001, nms=8),
+    "g_vga_blobs":     dict(h=480, w=640, seed=27, kind="blobs", border=15, conf=0.001, nms=15),
+}

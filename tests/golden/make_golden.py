@@ -115,6 +115,20 @@ def main():
         nk[name + ".score"] = nms.ravel()[flat].astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "nms_topk.npz"), **nk)
 
+    # ---------------- greedy nms_fast path of the demo (no sub-pixel: torchgeometry is not installed) --------
+    gk = {}
+    for name, spec in cases.GREEDY_CASES.items():
+        score = cases.nms_input(spec)
+        rb = RT.remove_borders(score, borders=spec["border"])
+        pts = RT.get_points_direct_from_score_map(heatmap=rb, conf_thresh=spec["conf"], nms_size=spec["nms"],
+                                                  subpixel=False, order_coord="xysr")
+        if pts.size == 0:
+            gk[name + ".idx"] = np.zeros(0, np.int32); gk[name + ".score"] = np.zeros(0, np.float32)
+        else:
+            gk[name + ".idx"] = (pts[:, 1].astype(np.int64) * score.shape[1] + pts[:, 0].astype(np.int64)).astype(np.int32)
+            gk[name + ".score"] = pts[:, 3].astype(np.float32)      # emitted sorted by confidence, descending
+    np.savez_compressed(os.path.join(HERE, "greedy_nms.npz"), **gk)
+
     # ---------------- geometry, state-dict table, loader behaviour ----------------
     geo = {"pad": {}, "state": [], "loader": {}}
     for (h, w) in cases.PAD_SIZES:

@@ -1,0 +1,56 @@
+"""HIP greedy NMS (demo post-processing) against the reference's golden vectors and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", list(cases.GREEDY_CASES))
+def test_greedy_golden(name):
+    from balf_amd import ops
+    f = np.load(os.path.join(G, "greedy_nms.npz"))
+    spec = cases.GREEDY_CASES[name]
+    score = cases.nms_input(spec)
+    t = torch.from_numpy(score).cuda().unsqueeze(0)
+    idx, sc, _, cnt, tot = ops.greedy_nms(t, 0, 0, spec["h"], spec["w"], spec["border"], spec["conf"], spec["nms"], 4096)
+    n = int(cnt[0])
+    assert n == int(tot[0]) == f[name + ".idx"].size
+    assert np.array_equal(idx[0, :n].cpu().numpy(), f[name + ".idx"])            # same points, same order
+    assert np.array_equal(sc[0, :n].cpu().numpy().view(np.uint32), f[name + ".score"].view(np.uint32))
+    assert np.all(idx[0, n:].cpu().numpy() == -1)
+
+
+def test_greedy_batch_crop_vs_oracle_1080p():
+    from balf_amd import ops
+    rng = np.random.default_rng(3)
+    hp, wp, h, w, top, left = 1088, 1920, 1080, 1920, 4, 0
+    prob = rng.random((2, hp, wp), dtype=np.float32)
+    t = torch.from_numpy(prob).cuda()
+    idx, sc, xy, cnt, tot = ops.greedy_nms(t, top, left, h, w, 15, 0.001, 15, 2048, subpixel_patch=4)
+    for b in range(2):
+        rb = O.remove_borders(prob[b, top:top + h, left:left + w], 15)
+        ri, rs = O.greedy_nms(rb, 0.001, 15)
+        n = int(cnt[b])
+        assert int(tot[b]) == ri.size and n == min(2048, ri.size)
+        assert np.array_equal(idx[b, :n].cpu().numpy(), ri[:n].astype(np.int32))
+        ref_xy = O.soft_argmax_refine(rb, ri[:n], 4)
+        assert np.abs(xy[b, :n].cpu().numpy() - ref_xy).max() < 1e-3
+
+
+def test_mirror_function():
+    from balf_amd.utils import test_utils as T
+    f = np.load(os.path.join(G, "greedy_nms.npz"))
+    name = "g_blobs_240x320"
+    spec = cases.GREEDY_CASES[name]
+    rb = T.remove_borders(cases.nms_input(spec), spec["border"])
+    pts = T.get_points_direct_from_score_map(heatmap=rb, conf_thresh=spec["conf"], nms_size=spec["nms"], subpixel=False)
+    assert pts.dtype == np.float64 and pts.shape == (f[name + ".idx"].size, 4)
+    assert np.array_equal((pts[:, 1] * spec["w"] + pts[:, 0]).astype(np.int32), f[name + ".idx"])
+    assert T.get_points_direct_from_score_map(np.zeros((64, 64), np.float32), conf_thresh=0.001).shape == (0, 4)

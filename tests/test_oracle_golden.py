@@ -108,3 +108,14 @@ def test_geometry_and_state_table():
     ents = arch.state_entries()
     assert [[n, list(s), d] for n, s, d in ents] == geo["state"]
     assert len(ents) == 167
+
+
+@pytest.mark.parametrize("name", list(cases.GREEDY_CASES))
+def test_greedy_nms_cases(name):
+    """The demo's get_points_direct_from_score_map(subpixel=False), captured from the reference."""
+    f = np.load(os.path.join(G, "greedy_nms.npz"))
+    spec = cases.GREEDY_CASES[name]
+    rb = O.remove_borders(cases.nms_input(spec), spec["border"])
+    idx, sc = O.greedy_nms(rb, spec["conf"], spec["nms"])
+    assert np.array_equal(idx.astype(np.int32), f[name + ".idx"])
+    assert np.array_equal(sc.astype(np.float32).view(np.uint32), f[name + ".score"].view(np.uint32))
