@@ -46,7 +46,16 @@ __device__ __forceinline__ f4 mfma16x3(const HL &a, const HL &b, f4 c) {
     return mfma16(a.hi, b.hi, c);
 }
 
+#ifndef BALF_ABLATE_SPLIT
+#define BALF_ABLATE_SPLIT 0
+#endif
 __device__ __forceinline__ void split_pair(float v0, float v1, h2 &hi, h2 &lo) {
+    if (BALF_ABLATE_SPLIT) {                       // timing experiment: one convert, no residual
+        typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
+        const fp16x2_ h_ = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+        hi = __builtin_bit_cast(h2, h_); lo = hi;
+        return;
+    }
     typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
     const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);      // hi = rtz_f16(v); v - hi is exact in fp32
     hi = __builtin_bit_cast(h2, h);
@@ -381,6 +390,40 @@ __device__ __forceinline__ void gemm16_single(f4 (&acc)[2][P], const WPre &w, BL
         for (int p = 0; p < P; ++p) acc[nt][p] = mfma16(w.a[nt].hi, b[p].hi, acc[nt][p]);
 }
 
+#ifndef BALF_ABLATE_STORE
+#define BALF_ABLATE_STORE 0
+#endif
+#ifndef BALF_ABLATE_MIX
+#define BALF_ABLATE_MIX 0
+#endif
+#ifndef BALF_ABLATE_SPLIT
+#define BALF_ABLATE_SPLIT 0
+#endif
+// In-kernel stamps (diagnostic build -DBALF_STAMPS=1 only): wave 0 / lane 0 of every workgroup adds the cycles
+// between consecutive STAMP(i) points to g_stamp_sum[kernel][i]; balf_debug_stamps() reads them back.
+#ifndef BALF_STAMPS
+#define BALF_STAMPS 0
+#endif
+#if BALF_STAMPS
+__device__ unsigned long long g_stamp_sum[16][24];
+__device__ unsigned long long g_stamp_cnt[16];
+#define STAMP_DECL unsigned long long st_prev = 0; (void)st_prev
+#define STAMP(i)                                                                                        \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        unsigned long long st_now;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if (threadIdx.x == 0) {                                                                         \
+            if ((i) > 0) atomicAdd(&g_stamp_sum[STAMP_KID][(i)], st_now - st_prev);                     \
+            else atomicAdd(&g_stamp_cnt[STAMP_KID], 1ull);                                              \
+        }                                                                                               \
+        st_prev = st_now;                                                                               \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
 constexpr int kBtPitch16 = kTokens + 8;        // halves per channel row of the transposed token tile
 
 #ifndef BALF_COOP_MIN_C
@@ -405,8 +448,11 @@ constexpr int stage_lds_bytes16() {
 template <int C, int CIN, int MODE>
 __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(StageArgs A) {
     constexpr bool PK = (MODE == 0) && (C == 32);      // packed VALU math only where it measured faster
+    constexpr int STAMP_KID = (C == 32 ? 0 : C == 64 ? 1 : C == 128 ? 2 : 3) * 2 + MODE; (void)STAMP_KID;
+    STAMP_DECL;
     constexpr int P = StageP<C>::P;
     constexpr int NT = C / 16, KS = C / 32;
+    STAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int main_bytes =
         stage_lds_bytes16<C, P>() - 4 * C * 4 - (use_ring<C>() ? kRingBytes : 0) - par_floats<C>() * 4;
@@ -424,8 +470,14 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     const int H = A.H, W = A.W;
     const int cols = W / 8 / P;
     const int per_img = (H / 8) * cols;
-    const int n = blockIdx.x / per_img;
-    const int rem = blockIdx.x - n * per_img;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the blocks that share an L2).  Give
+    // each XCD a contiguous range of work items so that neighbouring items -- which read the same cache lines
+    // of the strided stage-1 gather -- hit one L2 instead of eight.  Speed only: any placement is correct.
+    const int nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xl = blockIdx.x & 7, xj = blockIdx.x >> 3;
+    const int item = (xl < xr ? xl * (xq + 1) : xr * (xq + 1) + (xl - xr) * xq) + xj;
+    const int n = item / per_img;
+    const int rem = item - n * per_img;
     const int iy0 = rem / cols, ix0 = (rem - iy0 * cols) * P;
     const int tok = 16 * wave + li, ty = tok >> 3, tx = tok & 7;
     long pix[P];
@@ -470,8 +522,21 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     //  kernel's later read was tried: FETCH_SIZE doubled for that tensor and the kernel got no faster.)
     float in[P][3];
     if constexpr (CIN == 3) {
+        if (MODE == 0 && P == 4 && A.u8_ch == 0) {
+            // grid kernel, float input: the lane's four pixels are adjacent in x (16-byte aligned: W and the
+            // group offset are multiples of 4) -> one 16-byte load per colour plane instead of four scalar ones
+            const long hw = (long)H * W;
+            const long o = (long)py[0] * W + px_[0];
 #pragma unroll
-        for (int p = 0; p < P; ++p) load_input3(A, blob + kLayout.u8_lut, n, py[p], px_[p], in[p]);
+            for (int k = 0; k < 3; ++k) {
+                const f4 v = ldg4(A.X + ((long)n * 3 + k) * hw + o);
+#pragma unroll
+                for (int p = 0; p < P; ++p) in[p][k] = v[p];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < P; ++p) load_input3(A, blob + kLayout.u8_lut, n, py[p], px_[p], in[p]);
+        }
     }
     if constexpr (use_ring<C>() && CIN != 3) {
         // stage input as the first Linear's B operand, staged through the wave's slot: an ordinary global
@@ -512,7 +577,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
         }
         __syncthreads();
     }
-
+    STAMP(1);   // prologue: inputs, ring prime, parameter cache
 
     WPre wpre;                                         // stage 1: weights of the next Linear
     if constexpr (!use_ring<C>() && NT == 2) wpre = wpre_load(seq[1], lane);
@@ -580,6 +645,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
         layernorm_plain<PK>(x0, h);
         store_slot16(slot, h, lane);
     }
+    STAMP(2);   // x0 (VALU or GEMM) + LN + slot
     auto from_slot = [&](int kk, int p) {
         HL o;
         o.hi = slot[((kk * P + p) * 2 + 0) * 64 + lane];
@@ -590,22 +656,26 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     init_bias(z, par + kParQ1B * C, q);
     G(I1{}, z, from_slot);
     gelu<PK>(z);
+    STAMP(3);   // dense1 half + GELU
 
     {
         f4 h[NT][P];
         layernorm_plain<PK>(z, h);
         store_slot16(slot, h, lane);
     }
+    STAMP(4);   // LN + slot
     f4 ga[NT][P];
     init_bias(ga, par + kParD1B * C, q);
     G(I2{}, ga, from_slot);
     gelu<PK>(ga);
+    STAMP(5);   // branch dense1 (a half) + GELU
     {
         f4 gb[NT][P];
         init_bias(gb, par + kParD1B * C + C, q);
         G(I3{}, gb, from_slot);
         gelu<PK>(gb);
         layernorm<PK>(gb, gb, par + kParGlnG * C, par + kParGlnB * C, q);
+        STAMP(6);   // branch dense1 (b half) + GELU + LN
         lds_barrier();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -621,6 +691,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
             }
     }
     lds_barrier();
+    STAMP(7);   // transposed tile written + barrier
     {
         // mix^T[c][g'] = sum_g bT[c][g] * Wmix[g'][g]: A = bT rows (channels), B = natural-order Wmix fragments
         HL w0, w1;
@@ -663,6 +734,14 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
                 for (int r = 0; r < 4; ++r) ga[ct][p][r] *= (m[r] + mb1);
             }
     }
+    STAMP(8);   // token mix (+ mix weights from the ring)
+    HL ub32[(!use_ring<C>() && MODE == 1) ? KS : 1][P];   // stage 1 block kernel: u' rows requested now, used by the
+    if constexpr (!use_ring<C>() && MODE == 1) {           // RSHMAG dense2 three Linears later (HBM latency hidden)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int p = 0; p < P; ++p) ub32[kk][p] = load_frag_px(A.U, pix[p], C, kk, q);
+    }
     lds_barrier();
     store_slot16(slot, ga, lane);
     f4 o[NT][P];
@@ -673,12 +752,14 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
 #pragma unroll
         for (int p = 0; p < P; ++p) o[nt][p] += z[nt][p];
 
+    STAMP(9);   // gate -> slot, dense2, residual
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                store_frag_px(A.U, pix[p], C, ks, q, split8(o[2 * ks][p], o[2 * ks + 1][p]));
+                if (!BALF_ABLATE_STORE || o[2 * ks][p][0] == 1.2345e-33f) store_frag_px(A.U, pix[p], C, ks, q, split8(o[2 * ks][p], o[2 * ks + 1][p]));
+        STAMP(10);  // u' store
         return;
     } else {
         store_slot16(slot, o, lane);
@@ -701,8 +782,9 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
             G(I7{}, x1, from_slot);
         } else {
             G(I6{}, x1, from_slot);
-            G(I7{}, x1, [&](int kk, int p) { return load_frag_px(A.U, pix[p], C, kk, q); });
+            G(I7{}, x1, [&](int kk, int p) { return ub32[kk][p]; });
         }
+        STAMP(10);  // dense2 of the RSHMAG over cat[u', v'] (u' from HBM)
         if constexpr (CIN == 3) stage1_x0(x0);         // recomputed (3 MACs/channel): frees 32 registers across
                                                        // the whole block branch (bit-identical to the first time)
 #pragma unroll
@@ -710,15 +792,17 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 x1[nt][p] += x0[nt][p];
-                *reinterpret_cast<f4 *>(A.R + pix[p] * C + 16 * nt + 4 * q) = x1[nt][p] + x0[nt][p];
+                if (!BALF_ABLATE_STORE || x1[nt][p][0] == 1.2345e-33f) *reinterpret_cast<f4 *>(A.R + pix[p] * C + 16 * nt + 4 * q) = x1[nt][p] + x0[nt][p];
             }
         layernorm_plain<PK>(x1, x1);
         store_slot16(slot, x1, lane);
+        STAMP(11);  // x0 recompute, R store, LN, slot
         f4 m1[NT][P];
         init_bias(m1, par + kParR1B * C + 64, q);
         G(I8{}, m1, from_slot);
         lrelu(m1);
         store_slot16(slot, m1, lane);
+        STAMP(12);  // conv1 + lrelu + slot
         f4 t[NT][P];
         init_bias(t, par + kParR2B * C + 64, q);
         G(I9{}, t, from_slot);
@@ -727,7 +811,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
             f4 s = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                *reinterpret_cast<f4 *>(A.T + pix[p] * C + 16 * nt + 4 * q) = t[nt][p];
+                if (!BALF_ABLATE_STORE || t[nt][p][0] == 1.2345e-33f) *reinterpret_cast<f4 *>(A.T + pix[p] * C + 16 * nt + 4 * q) = t[nt][p];
                 s += t[nt][p];
             }
 #pragma unroll
@@ -740,9 +824,11 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
                 if (li == 0) red[wave * C + 16 * nt + 4 * q + r] = v;
             }
         }
+        STAMP(13);  // conv2, T store, channel sums
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256)
-            A.partial[(long)blockIdx.x * C + c] = (red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c]);
+            A.partial[(long)item * C + c] = (red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c]);
+        STAMP(14);  // partial sums out
     }
 }
 
@@ -890,6 +976,19 @@ int run_pool16(int s, const float *T, const float *R, const float *scale, int B,
 }
 
 }  // namespace
+
+#if BALF_STAMPS
+extern "C" int balf_debug_stamps(unsigned long long *sums /*[16*24]*/, unsigned long long *cnt /*[16]*/, int reset) {
+    if (hipMemcpyFromSymbol(sums, HIP_SYMBOL(g_stamp_sum), sizeof(g_stamp_sum)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_stamp_cnt), sizeof(g_stamp_cnt)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[16 * 24];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), z, sizeof(g_stamp_sum)) != hipSuccess) return -1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cnt), z, sizeof(g_stamp_cnt)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, int B, int Hp, int Wp, float *logits_dev,
                 float *prob_dev, char *ws, const Plan &pl, hipStream_t st) {
