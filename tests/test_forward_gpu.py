@@ -140,6 +140,20 @@ def test_batch_invariance_and_determinism(model):
     assert torch.equal(a, c)                      # per-image results do not depend on the batch
 
 
+@pytest.mark.parametrize("which", ["fp32", "fp16"])
+def test_micro_batch_boundary_is_invisible(model, model16, which):
+    """balf_forward walks the batch in micro-batches (8 images at 1088x1920): image 8 of a batch of 9 lives in
+    the second micro-batch and must come out exactly as when it is run alone."""
+    m = model if which == "fp32" else model16
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.rand(9, 3, 1088, 1920, generator=g).to("cuda:0")
+    with torch.inference_mode():
+        full = m(x, want_logits=False)["prob"]
+        last = m(x[8:9].contiguous(), want_logits=False)["prob"]
+        first = m(x[0:1].contiguous(), want_logits=False)["prob"]
+    assert torch.equal(full[8:9], last) and torch.equal(full[0:1], first)
+
+
 def test_forward_vs_oracle_fp64_larger(model):
     """A size the goldens do not hold (micro-batching + odd aspect): compare with the fp64 oracle."""
     sd = O.cast_state(synth.synthetic_state_dict(cases.WEIGHT_SEED), torch.float64)
