@@ -36,6 +36,17 @@ PROTOTYPES = {
     "balf_greedy_nms_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "balf_greedy_nms": (_i, [_fp, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _vp, _fp, _fp, _vp, _vp, _vp,
                             _sz, _vp]),
+    "balf_hardnet_num_state_tensors": (_i, []),
+    "balf_hardnet_state_tensor_name": (C.c_char_p, [_i]),
+    "balf_hardnet_state_tensor_numel": (_sz, [_i]),
+    "balf_hardnet_packed_weights_bytes": (_sz, []),
+    "balf_hardnet_pack_weights": (_i, [C.POINTER(_vp), _i, _vp, _sz]),
+    "balf_hardnet_workspace_bytes": (_sz, [_i]),
+    "balf_hardnet_forward": (_i, [_vp, _fp, _i, _fp, _vp, _sz, _vp]),
+    "balf_extract_patches_workspace_bytes": (_sz, [_i, _i, C.c_float]),
+    "balf_extract_patches": (_i, [_vp, _i, _i, _fp, _i, C.c_float, _fp, _vp, _sz, _vp]),
+    "balf_match_smnn_workspace_bytes": (_sz, [_i, _i]),
+    "balf_match_smnn": (_i, [_fp, _i, _fp, _i, C.c_float, _vp, _fp, _vp, _vp, _sz, _vp]),
     "balf_profile_num_slots": (_i, []),
     "balf_profile_slot_name": (C.c_char_p, [_i]),
     "balf_profile_begin": (_i, []),

@@ -9,7 +9,7 @@ pids=()
 for f in *.hip; do
   o=obj/${f%.hip}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/balf_hip.h -nt "$o" ] || \
-     { [ -f "${f%.hip}.h" ] && [ "${f%.hip}.h" -nt "$o" ]; } || { [ -f layout.h ] && [ layout.h -nt "$o" ]; } || [ prof.h -nt "$o" ] || [ det_common.h -nt "$o" ]; then
+     { [ -f "${f%.hip}.h" ] && [ "${f%.hip}.h" -nt "$o" ]; } || { [ -f layout.h ] && [ layout.h -nt "$o" ]; } || [ prof.h -nt "$o" ] || [ det_common.h -nt "$o" ] || [ split16.h -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi

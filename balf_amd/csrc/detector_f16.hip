@@ -24,44 +24,10 @@
 #include <type_traits>
 
 #include "det_common.h"
+#include "split16.h"
 
 namespace balf {
 namespace {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-
-struct HL {
-    h8 hi, lo;
-};
-
-__device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-// three-product accumulate: (ah + al)(bh + bl) ~ ah bh + al bh + ah bl
-__device__ __forceinline__ f4 mfma16x3(const HL &a, const HL &b, f4 c) {
-    c = mfma16(a.lo, b.hi, c);
-    c = mfma16(a.hi, b.lo, c);
-    return mfma16(a.hi, b.hi, c);
-}
-
-#ifndef BALF_ABLATE_SPLIT
-#define BALF_ABLATE_SPLIT 0
-#endif
-__device__ __forceinline__ void split_pair(float v0, float v1, h2 &hi, h2 &lo) {
-    if (BALF_ABLATE_SPLIT) {                       // timing experiment: one convert, no residual
-        typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
-        const fp16x2_ h_ = __builtin_amdgcn_cvt_pkrtz(v0, v1);
-        hi = __builtin_bit_cast(h2, h_); lo = hi;
-        return;
-    }
-    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);      // hi = rtz_f16(v); v - hi is exact in fp32
-    hi = __builtin_bit_cast(h2, h);
-    const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(fmaf((float)hi[0], -1.0f, v0), fmaf((float)hi[1], -1.0f, v1));
-    lo = __builtin_bit_cast(h2, l);
-}
 
 // two accumulator tiles (channels 16*2s + 4q + r and 16*(2s+1) + 4q + r) -> one K-step B fragment
 __device__ __forceinline__ HL split8(const f4 &t0, const f4 &t1) {

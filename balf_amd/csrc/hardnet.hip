@@ -1,0 +1,516 @@
+// HardNet patch descriptor on gfx950 (the descriptor of the demo path).
+//
+// Reference: /root/reference/third_party/hardnet/hardnet_pytorch.py:31-72 -- per-patch (mean, unbiased std)
+// normalisation of a 32x32 patch, six [conv3x3 -> BatchNorm(eval, affine=False) -> ReLU] layers
+// (1->32, 32->32, 32->64 /2, 64->64, 64->128 /2, 128->128), a valid 8x8 convolution 128->128 + BatchNorm, and
+// x / sqrt(sum x^2 + 1e-10).  Called per 1000 patches from demo/demo_match.py:72-93.
+//
+// Every convolution is an implicit GEMM  D[co][pixel] = sum_{tap,ci} W[co][tap,ci] * act[ci][pixel + tap]  on
+// v_mfma_f32_16x16x32_f16 with split operands (split16.h): activations live in HBM and LDS as two f16 planes
+// (hi, lo), channel-fastest ([y][x][c]), so that the B operand of a K-step (32 input channels of one tap) is a
+// single 16-byte LDS read per plane, shifted per tap by an address offset only -- no im2col buffer.  The LDS
+// image of the input band carries a one-pixel zero frame (the convolution padding) and XOR-swizzles the 16-byte
+// chunk index with the pixel index, which makes the 16 pixels of an MFMA column tile hit 16 different bank
+// groups without padding bytes.  BatchNorm is folded into the packed weights (scale) and a bias on the host.
+//
+//   hn_conv_kernel<L2>   patch normalisation + conv1 (K = 9 padded to one K-step) computed into LDS for the band,
+//                        then conv2; a1 never exists in HBM
+//   hn_conv_kernel<L3..L6>
+//   hn_fc_kernel         the 8x8 valid convolution as a [128 x 8192] x [8192 x patches] GEMM, B operand straight
+//                        from HBM, fused BatchNorm bias + L2 normalisation
+//
+// A workgroup is 4 waves; a wave owns 2 output-channel tiles x 4 pixel tiles (8 accumulator tiles).  Weights are
+// read from global memory (L2-resident, <= 576 KiB per layer) in A-fragment order, one K-step ahead.
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "prof.h"
+#include "split16.h"
+
+namespace balf {
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kPS = 32;                       // patch side
+constexpr int kDesc = 128;
+constexpr int kFcK = 8 * 8 * 128;
+
+// ---- packed blob ---------------------------------------------------------------------------------
+// weights of layer l: [K-step][channel tile][plane hi|lo][lane][8 halves]; k = (ky*KW + kx)*CIN + ci.
+struct HnConv { int cin, cout, ksz; };
+constexpr HnConv kConv[7] = {{1, 32, 3}, {32, 32, 3}, {32, 64, 3}, {64, 64, 3}, {64, 128, 3}, {128, 128, 3}, {128, 128, 8}};
+constexpr int kFeatIdx[7] = {0, 3, 6, 9, 12, 15, 19};
+
+constexpr size_t hn_ksteps(int l) { return l == 0 ? 1 : (size_t)kConv[l].ksz * kConv[l].ksz * kConv[l].cin / 32; }
+constexpr size_t hn_wbytes(int l) { return hn_ksteps(l) * (kConv[l].cout / 16) * 2048; }
+constexpr size_t hn_woff(int l) { return l == 0 ? 0 : hn_woff(l - 1) + hn_wbytes(l - 1) + (size_t)kConv[l - 1].cout * 4; }
+constexpr size_t hn_boff(int l) { return hn_woff(l) + hn_wbytes(l); }
+constexpr size_t kHnBlobBytes = hn_boff(6) + 128 * 4;
+
+struct HnState { std::string name; size_t numel; };
+const std::vector<HnState> &hn_table() {
+    static const std::vector<HnState> t = [] {
+        std::vector<HnState> v;
+        for (int l = 0; l < 7; ++l) {
+            const std::string c = "features." + std::to_string(kFeatIdx[l]);
+            const std::string b = "features." + std::to_string(kFeatIdx[l] + 1);
+            v.push_back({c + ".weight", (size_t)kConv[l].cout * kConv[l].cin * kConv[l].ksz * kConv[l].ksz});
+            v.push_back({b + ".running_mean", (size_t)kConv[l].cout});
+            v.push_back({b + ".running_var", (size_t)kConv[l].cout});
+        }
+        return v;
+    }();
+    return t;
+}
+
+// ---- device helpers ------------------------------------------------------------------------------
+__device__ __forceinline__ h8 zero8() {
+    h8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (_Float16)0.0f;
+    return z;
+}
+
+template <int CH>
+__device__ __forceinline__ int swz(int q) {
+    constexpr int SH = CH == 4 ? 2 : (CH == 8 ? 1 : 0);
+    return (q >> SH) & (CH - 1);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int CIN_, int COUT_, int HIN_, int STRIDE_, int OROWS_, bool FUSE1_>
+struct ConvCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, STRIDE = STRIDE_, OROWS = OROWS_;
+    static constexpr bool FUSE1 = FUSE1_;
+    static constexpr int HOUT = HIN / STRIDE, WP = HIN + 2, IR = (OROWS - 1) * STRIDE + 3;
+    static constexpr int NPIX = OROWS * HOUT, NT = NPIX / 16, MT = COUT / 16, WM = 2, WN = 4;
+    static constexpr int MG = MT / WM, NG = NT / WN;
+    static constexpr int KPT = CIN / 32, KS = 9 * KPT, CH = CIN / 8;
+    static constexpr int NQ = IR * WP;                          // LDS pixels per plane
+    static constexpr int PLANE_BYTES = NQ * CIN * 2;
+    static constexpr int BANDS = HOUT / OROWS;
+    static constexpr int INP_FLOATS = FUSE1 ? 34 * 34 : 0;
+    static constexpr int LDS_BYTES = 2 * PLANE_BYTES + INP_FLOATS * 4 + 64;
+    static_assert(MG * NG == 4, "4 waves per workgroup");
+    static_assert(HOUT % OROWS == 0 && NPIX % 64 == 0, "band shape");
+};
+
+struct ConvArgs {
+    const void *in;          // FUSE1: float patches [N][32][32]; else f16 planes [N][2][HIN][HIN][CIN]
+    void *out;               // f16 planes [N][2][HOUT][HOUT][COUT]
+    const char *w;           // this layer's fragments
+    const float *bias;
+    const char *w1;          // FUSE1: conv1 fragments + bias
+    const float *bias1;
+    int n_patches;
+};
+
+template <typename Cfg>
+__global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, HIN = Cfg::HIN, S = Cfg::STRIDE, HOUT = Cfg::HOUT, WP = Cfg::WP;
+    constexpr int WM = Cfg::WM, WN = Cfg::WN, MT = Cfg::MT, CH = Cfg::CH, KPT = Cfg::KPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *act = smem;                                       // [plane][q][CIN] halves, chunk-swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int patch = blockIdx.x / Cfg::BANDS, band = blockIdx.x % Cfg::BANDS;
+    const int r0 = band * Cfg::OROWS;                       // first output row
+    const int r_in0 = r0 * S - 1;                           // input row of LDS row 0
+
+    if constexpr (Cfg::FUSE1) {
+        // ---- patch normalisation (hardnet_pytorch.py:58-63) ----
+        float *inp = reinterpret_cast<float *>(smem + 2 * Cfg::PLANE_BYTES);        // [34][34], zero frame
+        float *red = inp + 34 * 34;
+        const float *src = static_cast<const float *>(a.in) + (size_t)patch * (kPS * kPS);
+        const f4 v = *reinterpret_cast<const f4 *>(src + 4 * tid);
+        for (int i = tid; i < 34 * 34; i += 256) inp[i] = 0.0f;
+        float s = wave_sum(v[0] + v[1] + v[2] + v[3]);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / 1024.0f);
+        const f4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+        s = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+        if (lane == 0) red[4 + wave] = s;
+        __syncthreads();
+        const float sd = sqrtf((red[4] + red[5] + red[6] + red[7]) * (1.0f / 1023.0f)) + 1e-7f;
+        const int py = (4 * tid) >> 5, px = (4 * tid) & 31;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) inp[(py + 1) * 34 + px + 1 + j] = d[j] / sd;
+        __syncthreads();
+
+        // ---- conv1 + BN + ReLU for the band's 10 x 34 pixel frame, straight into the LDS image ----
+        HL a1[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            a1[m].hi = *reinterpret_cast<const h8 *>(a.w1 + (m * 2 + 0) * 1024 + lane * 16);
+            a1[m].lo = *reinterpret_cast<const h8 *>(a.w1 + (m * 2 + 1) * 1024 + lane * 16);
+        }
+        constexpr int NQT = (Cfg::NQ + 15) / 16;
+        for (int t = wave; t < NQT; t += 4) {
+            const int q = 16 * t + n;
+            const int iy = q / WP, ixp = q - iy * WP;
+            const int y = r_in0 + iy, x = ixp - 1;
+            const bool inside = q < Cfg::NQ && y >= 0 && y < HIN && x >= 0 && x < HIN;
+            const int yc = inside ? y : 0, xc = inside ? x : 0;
+            float tv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tv[j] = 0.0f;
+            if (g == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tv[j] = inp[(yc + j / 3) * 34 + xc + j % 3];
+            } else if (g == 1) {
+                tv[0] = inp[(yc + 2) * 34 + xc + 2];
+            }
+            HL b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h2 hh, ll;
+                split_pair(tv[2 * j], tv[2 * j + 1], hh, ll);
+                b.hi[2 * j] = hh[0]; b.hi[2 * j + 1] = hh[1];
+                b.lo[2 * j] = ll[0]; b.lo[2 * j + 1] = ll[1];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+                c = mfma16x3(a1[m], b, c);
+                const f4 bb = *reinterpret_cast<const f4 *>(a.bias1 + 16 * m + 4 * g);
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = inside ? fmaxf(c[r] + bb[r], 0.0f) : 0.0f;
+                h2 h01, l01, h23, l23;
+                split_pair(o[0], o[1], h01, l01);
+                split_pair(o[2], o[3], h23, l23);
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 hv = {h01[0], h01[1], h23[0], h23[1]};
+                const h4 lv = {l01[0], l01[1], l23[0], l23[1]};
+                if (q < Cfg::NQ) {
+                    const int off = q * (CIN * 2) + (((2 * m + (g >> 1)) ^ swz<CH>(q)) << 4) + (g & 1) * 8;
+                    *reinterpret_cast<h4 *>(act + off) = hv;
+                    *reinterpret_cast<h4 *>(act + Cfg::PLANE_BYTES + off) = lv;
+                }
+            }
+        }
+    } else {
+        // ---- copy the input band (both planes) into the swizzled LDS image, zero frame included ----
+        const _Float16 *in = static_cast<const _Float16 *>(a.in) + (size_t)patch * 2 * HIN * HIN * CIN;
+        constexpr int TOTAL = 2 * Cfg::NQ * CH;
+#pragma unroll 4
+        for (int i = tid; i < TOTAL; i += 256) {
+            const int plane = i / (Cfg::NQ * CH);
+            const int rem = i - plane * (Cfg::NQ * CH);
+            const int q = rem / CH, c = rem - q * CH;
+            const int iy = q / WP, ixp = q - iy * WP;
+            const int y = r_in0 + iy, x = ixp - 1;
+            h8 v = zero8();
+            if (y >= 0 && y < HIN && x >= 0 && x < HIN)
+                v = *reinterpret_cast<const h8 *>(in + ((size_t)(plane * HIN + y) * HIN + x) * CIN + c * 8);
+            *reinterpret_cast<h8 *>(act + plane * Cfg::PLANE_BYTES + q * (CIN * 2) + ((c ^ swz<CH>(q)) << 4)) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- implicit GEMM over 9 taps x CIN ----
+    const int mg = wave / Cfg::NG, ng = wave % Cfg::NG;
+    int q0[WN];
+#pragma unroll
+    for (int t = 0; t < WN; ++t) {
+        const int p = 16 * (ng * WN + t) + n;
+        const int oy = p / HOUT, ox = p - oy * HOUT;
+        q0[t] = oy * S * WP + ox * S;
+    }
+    f4 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int t = 0; t < WN; ++t) acc[m][t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const char *wl = a.w + (size_t)(mg * WM) * 2048 + lane * 16;
+    auto load_a = [&](int ks, HL (&dst)[WM]) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            const char *p = wl + ((size_t)ks * MT + m) * 2048;
+            dst[m].hi = *reinterpret_cast<const h8 *>(p);
+            dst[m].lo = *reinterpret_cast<const h8 *>(p + 1024);
+        }
+    };
+    HL acur[WM];
+    load_a(0, acur);
+    int ks = 0;
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            int qb[WN], sw[WN];
+#pragma unroll
+            for (int t = 0; t < WN; ++t) {
+                const int q = q0[t] + ky * WP + kx;
+                qb[t] = q * (CIN * 2);
+                sw[t] = swz<CH>(q);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KPT; ++kk, ++ks) {
+                HL anext[WM];
+                load_a(ks + 1 < Cfg::KS ? ks + 1 : ks, anext);
+                HL b[WN];
+#pragma unroll
+                for (int t = 0; t < WN; ++t) {
+                    const int off = qb[t] + (((kk * 4 + g) ^ sw[t]) << 4);
+                    b[t].hi = *reinterpret_cast<const h8 *>(act + off);
+                    b[t].lo = *reinterpret_cast<const h8 *>(act + Cfg::PLANE_BYTES + off);
+                }
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(acur[m].lo, b[t].hi, acc[m][t]);
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(acur[m].hi, b[t].lo, acc[m][t]);
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(acur[m].hi, b[t].hi, acc[m][t]);
+#pragma unroll
+                for (int m = 0; m < WM; ++m) acur[m] = anext[m];
+            }
+        }
+    }
+
+    // ---- bias (folded BatchNorm) + ReLU, split, store both planes ----
+    _Float16 *out = static_cast<_Float16 *>(a.out) + (size_t)patch * 2 * HOUT * HOUT * COUT;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        const int co = 16 * (mg * WM + m) + 4 * g;
+        const f4 bb = *reinterpret_cast<const f4 *>(a.bias + co);
+#pragma unroll
+        for (int t = 0; t < WN; ++t) {
+            const int p = 16 * (ng * WN + t) + n;
+            const int oy = r0 + p / HOUT, ox = p % HOUT;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[m][t][r] + bb[r], 0.0f);
+            h2 h01, l01, h23, l23;
+            split_pair(o[0], o[1], h01, l01);
+            split_pair(o[2], o[3], h23, l23);
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 hv = {h01[0], h01[1], h23[0], h23[1]};
+            const h4 lv = {l01[0], l01[1], l23[0], l23[1]};
+            const size_t e = ((size_t)oy * HOUT + ox) * COUT + co;
+            *reinterpret_cast<h4 *>(out + e) = hv;
+            *reinterpret_cast<h4 *>(out + (size_t)HOUT * HOUT * COUT + e) = lv;
+        }
+    }
+}
+
+// The last layer: out[co][patch] = sum_k W7[co][k] a6[patch][k], k = (y*8 + x)*128 + c -- exactly the order a6 is
+// stored in.  64 patches per workgroup; wave w owns channel tiles 2w, 2w+1 for all four patch tiles.
+struct FcArgs {
+    const _Float16 *in;      // [N][2][8192]
+    float *desc;             // [N][128]
+    const char *w;
+    const float *bias;
+    int n_patches;
+};
+
+__global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
+    constexpr int WM = 2, WN = 4, MT = 8, KS = kFcK / 32;
+    __shared__ float ssq[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int p0 = blockIdx.x * 64;
+    const _Float16 *bp[WN];
+#pragma unroll
+    for (int t = 0; t < WN; ++t) {
+        int p = p0 + 16 * t + n;
+        p = p < a.n_patches ? p : a.n_patches - 1;
+        bp[t] = a.in + (size_t)p * 2 * kFcK + g * 8;
+    }
+    f4 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int t = 0; t < WN; ++t) acc[m][t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    const char *wl = a.w + (size_t)(wave * WM) * 2048 + lane * 16;
+#pragma unroll 2
+    for (int ks = 0; ks < KS; ++ks) {
+        HL wa[WM], b[WN];
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            const char *p = wl + ((size_t)ks * MT + m) * 2048;
+            wa[m].hi = *reinterpret_cast<const h8 *>(p);
+            wa[m].lo = *reinterpret_cast<const h8 *>(p + 1024);
+        }
+#pragma unroll
+        for (int t = 0; t < WN; ++t) {
+            b[t].hi = *reinterpret_cast<const h8 *>(bp[t] + ks * 32);
+            b[t].lo = *reinterpret_cast<const h8 *>(bp[t] + kFcK + ks * 32);
+        }
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16x3(wa[m], b[t], acc[m][t]);
+    }
+    // BatchNorm bias, then x / sqrt(sum x^2 + 1e-10) over the 128 channels of each patch (hardnet_pytorch.py:11-15)
+    float part[WN];
+#pragma unroll
+    for (int t = 0; t < WN; ++t) part[t] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        const f4 bb = *reinterpret_cast<const f4 *>(a.bias + 16 * (wave * WM + m) + 4 * g);
+#pragma unroll
+        for (int t = 0; t < WN; ++t) {
+            acc[m][t] += bb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[t] += acc[m][t][r] * acc[m][t][r];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < WN; ++t) {
+        part[t] += __shfl_xor(part[t], 16);
+        part[t] += __shfl_xor(part[t], 32);
+        if (g == 0) ssq[wave][16 * t + n] = part[t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < WN; ++t) {
+        const int pl = 16 * t + n, p = p0 + pl;
+        const float inv = 1.0f / sqrtf(ssq[0][pl] + ssq[1][pl] + ssq[2][pl] + ssq[3][pl] + 1e-10f);
+        if (p < a.n_patches) {
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+                *reinterpret_cast<f4 *>(a.desc + (size_t)p * kDesc + 16 * (wave * WM + m) + 4 * g) = acc[m][t] * inv;
+        }
+    }
+}
+
+using CfgL2 = ConvCfg<32, 32, 32, 1, 8, true>;
+using CfgL3 = ConvCfg<32, 64, 32, 2, 8, false>;
+using CfgL4 = ConvCfg<64, 64, 16, 1, 8, false>;
+using CfgL5 = ConvCfg<64, 128, 16, 2, 8, false>;
+using CfgL6 = ConvCfg<128, 128, 8, 1, 8, false>;
+
+constexpr size_t kBufA = (size_t)2 * 32 * 32 * 32 * 2;      // a2 (largest tenant): 128 KiB per patch
+constexpr size_t kBufB = (size_t)2 * 16 * 16 * 64 * 2;      // a3: 64 KiB per patch
+constexpr int kChunk = 4096;                                // patches per pass through the layer kernels
+
+template <typename Cfg>
+int launch_conv(int slot, const ConvArgs &a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&hn_conv_kernel<Cfg>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess)
+            return BALF_ERR_LAUNCH;
+        attr_set = true;
+    }
+    BALF_PROF(slot, st, (hn_conv_kernel<Cfg><<<a.n_patches * Cfg::BANDS, 256, Cfg::LDS_BYTES, st>>>(a)));
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}
+
+void pack_layer(char *blob, int l, const float *w, const float *mean, const float *var) {
+    const HnConv c = kConv[l];
+    const int taps = c.ksz * c.ksz, K = taps * c.cin, KS = (int)hn_ksteps(l), MT = c.cout / 16;
+    _Float16 *dst = reinterpret_cast<_Float16 *>(blob + hn_woff(l));
+    float *bias = reinterpret_cast<float *>(blob + hn_boff(l));
+    std::vector<double> rstd(c.cout);
+    for (int co = 0; co < c.cout; ++co) {
+        rstd[co] = 1.0 / sqrt((double)var[co] + 1e-5);
+        bias[co] = (float)(-(double)mean[co] * rstd[co]);
+    }
+    for (int ks = 0; ks < KS; ++ks)
+        for (int mt = 0; mt < MT; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = 16 * mt + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
+                    float v = 0.0f;
+                    if (k < K) {
+                        const int tap = k / c.cin, ci = k % c.cin;
+                        v = (float)((double)w[((size_t)co * c.cin + ci) * taps + tap] * rstd[co]);
+                    }
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const size_t tile = ((size_t)ks * MT + mt) * 1024;
+                    dst[tile + lane * 8 + j] = hi;
+                    dst[tile + 512 + lane * 8 + j] = lo;
+                }
+}
+
+}  // namespace
+}  // namespace balf
+
+using namespace balf;
+
+extern "C" int balf_hardnet_num_state_tensors(void) { return (int)hn_table().size(); }
+
+extern "C" const char *balf_hardnet_state_tensor_name(int i) {
+    if (i < 0 || i >= (int)hn_table().size()) return nullptr;
+    return hn_table()[i].name.c_str();
+}
+
+extern "C" size_t balf_hardnet_state_tensor_numel(int i) {
+    if (i < 0 || i >= (int)hn_table().size()) return 0;
+    return hn_table()[i].numel;
+}
+
+extern "C" size_t balf_hardnet_packed_weights_bytes(void) { return kHnBlobBytes; }
+
+extern "C" int balf_hardnet_pack_weights(const float *const *tensors, int n_tensors, void *packed_host,
+                                         size_t packed_bytes) {
+    if (!tensors || !packed_host || n_tensors != (int)hn_table().size()) return BALF_ERR_ARG;
+    if (packed_bytes < kHnBlobBytes) return BALF_ERR_WORKSPACE;
+    for (int i = 0; i < n_tensors; ++i)
+        if (!tensors[i]) return BALF_ERR_ARG;
+    memset(packed_host, 0, kHnBlobBytes);
+    for (int l = 0; l < 7; ++l)
+        pack_layer(static_cast<char *>(packed_host), l, tensors[3 * l], tensors[3 * l + 1], tensors[3 * l + 2]);
+    return BALF_OK;
+}
+
+extern "C" size_t balf_hardnet_workspace_bytes(int n_patches) {
+    if (n_patches <= 0) return 0;
+    const size_t c = n_patches < kChunk ? n_patches : kChunk;
+    return c * (kBufA + kBufB);
+}
+
+extern "C" int balf_hardnet_forward(const void *packed_dev, const float *patches_dev, int n_patches, float *desc_dev,
+                                    void *workspace_dev, size_t workspace_bytes, void *stream) {
+    if (!packed_dev || !patches_dev || !desc_dev || !workspace_dev || n_patches <= 0) return BALF_ERR_ARG;
+    if (workspace_bytes < balf_hardnet_workspace_bytes(n_patches)) return BALF_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char *blob = static_cast<const char *>(packed_dev);
+    const int chunk = n_patches < kChunk ? n_patches : kChunk;
+    char *bufA = static_cast<char *>(workspace_dev);
+    char *bufB = bufA + (size_t)chunk * kBufA;
+    auto bias = [&](int l) { return reinterpret_cast<const float *>(blob + hn_boff(l)); };
+    for (int c0 = 0; c0 < n_patches; c0 += chunk) {
+        const int n = n_patches - c0 < chunk ? n_patches - c0 : chunk;
+        int rc;
+        ConvArgs a{};
+        a.n_patches = n;
+        a.in = patches_dev + (size_t)c0 * kPS * kPS; a.out = bufA;
+        a.w = blob + hn_woff(1); a.bias = bias(1); a.w1 = blob + hn_woff(0); a.bias1 = bias(0);
+        if ((rc = launch_conv<CfgL2>(balf_prof::kHnConv2, a, st)) != BALF_OK) return rc;
+        a.in = bufA; a.out = bufB; a.w = blob + hn_woff(2); a.bias = bias(2);
+        if ((rc = launch_conv<CfgL3>(balf_prof::kHnConv3, a, st)) != BALF_OK) return rc;
+        a.in = bufB; a.out = bufA; a.w = blob + hn_woff(3); a.bias = bias(3);
+        if ((rc = launch_conv<CfgL4>(balf_prof::kHnConv4, a, st)) != BALF_OK) return rc;
+        a.in = bufA; a.out = bufB; a.w = blob + hn_woff(4); a.bias = bias(4);
+        if ((rc = launch_conv<CfgL5>(balf_prof::kHnConv5, a, st)) != BALF_OK) return rc;
+        a.in = bufB; a.out = bufA; a.w = blob + hn_woff(5); a.bias = bias(5);
+        if ((rc = launch_conv<CfgL6>(balf_prof::kHnConv6, a, st)) != BALF_OK) return rc;
+        FcArgs f{reinterpret_cast<const _Float16 *>(bufA), desc_dev + (size_t)c0 * kDesc, blob + hn_woff(6), bias(6), n};
+        BALF_PROF(balf_prof::kHnFc, st, (hn_fc_kernel<<<balf_ceil_div(n, 64), 256, 0, st>>>(f)));
+        BALF_LAUNCH_CHECK();
+    }
+    return BALF_OK;
+}

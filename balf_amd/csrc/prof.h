@@ -9,7 +9,17 @@ enum Slot {
     // stage s in 0..3: 4*s + {0 grid branch, 1 block branch, 2 squeeze-excite, 3 pool (stage 4: head)}
     kNmsTile = 16,
     kTopkSelect = 17,
-    kNumSlots = 18,
+    kHnConv2 = 18,          // HardNet descriptor: conv1+conv2 (fused), conv3..conv6, final 8x8 GEMM
+    kHnConv3 = 19,
+    kHnConv4 = 20,
+    kHnConv5 = 21,
+    kHnConv6 = 22,
+    kHnFc = 23,
+    kPatchPyr = 24,         // demo path: pyramid level, patch sampling, descriptor matching
+    kPatchSample = 25,
+    kMatchNN = 26,
+    kMatchMutual = 27,
+    kNumSlots = 28,
 };
 extern bool g_on;
 void before(int slot, hipStream_t st);

@@ -47,7 +47,9 @@ static const char *kSlotNames[balf_prof::kNumSlots] = {
     "stage2_grid_branch", "stage2_block_branch", "stage2_se", "stage2_pool",
     "stage3_grid_branch", "stage3_block_branch", "stage3_se", "stage3_pool",
     "stage4_grid_branch", "stage4_block_branch", "stage4_se", "stage4_head",
-    "nms_tile", "topk_select"};
+    "nms_tile", "topk_select",
+    "hardnet_conv1_2", "hardnet_conv3", "hardnet_conv4", "hardnet_conv5", "hardnet_conv6", "hardnet_fc",
+    "patch_pyrdown", "patch_sample", "match_nn", "match_mutual"};
 
 extern "C" int balf_profile_num_slots(void) { return balf_prof::kNumSlots; }
 

@@ -1,0 +1,74 @@
+"""The reference's matching demo with every stage on the GPU.
+
+Same function names and arguments as /root/reference/demo/demo_match.py:21-112 (``detect``, ``extract_features``,
+``extract_matches``); ``args`` is any object with the attributes of ``config.parse_test_config``
+(/root/reference/balf/configs/config.py:42-59): border_size, nms_size, num_features, s_mult, order_coord,
+heatmap_confidence_threshold, sub_pixel, patch_size.  Image decoding (PIL) and drawing (cv2) stay with the caller.
+
+detector -> balf_forward_u8, keypoints -> balf_greedy_nms (+ soft-argmax), patches -> balf_extract_patches,
+descriptors -> balf_hardnet_forward, matches -> balf_match_smnn.  The only host round trip is the final result.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .. import arch, ops
+
+DEFAULT_ARGS = SimpleNamespace(border_size=15, nms_size=15, num_features=2048, s_mult=60, order_coord="xysr",
+                               heatmap_confidence_threshold=0.001, sub_pixel=True, patch_size=4)
+_MAX_POINTS = 16384
+
+
+def _detect_gpu(args, im: np.ndarray, detector, device) -> torch.Tensor:
+    """[n,3] (x, y, 1) on the GPU, strongest first, at most args.num_features rows."""
+    if args.order_coord != "xysr":
+        raise NotImplementedError("the demo path is implemented for order_coord='xysr' (the reference default)")
+    img = torch.as_tensor(np.ascontiguousarray(im), device=device)
+    if img.dtype != torch.uint8:
+        raise ValueError("expected a uint8 image, as load_im returns it")
+    h, w = img.shape[:2]
+    hp, wp, top, left = arch.padded_hw(h, w)
+    with torch.inference_mode():
+        prob = detector.forward_u8(img.unsqueeze(0), want_logits=False)["prob"]
+        k = min(_MAX_POINTS, h * w)
+        idx, score, xy, count, total = ops.greedy_nms(prob, top, left, h, w, args.border_size,
+                                                      args.heatmap_confidence_threshold, args.nms_size, k,
+                                                      args.patch_size if args.sub_pixel else 0)
+    n = min(int(count[0].item()), int(args.num_features))
+    if args.sub_pixel:
+        pts = xy[0, :n]
+    else:
+        ii = idx[0, :n].long()
+        pts = torch.stack([(ii % w).float(), (ii // w).float()], dim=1)
+    return torch.cat([pts, torch.ones((n, 1), device=device)], dim=1)
+
+
+def detect(args, im, detector, device):
+    """demo_match.py:21-57: image [H,W,3] uint8 -> keypoints [n,3] = (x, y, 1), strongest first."""
+    pts = _detect_gpu(args, im, detector, device)
+    if pts.shape[0] == 0:
+        return np.zeros([0, 3])
+    return pts.double().cpu().numpy()
+
+
+def extract_features(args, im_rgb, im_gray, detector, descriptor, device):
+    """demo_match.py:59-95: -> (keypoints [n,2] float64 NumPy, descriptors [n,128] float32 NumPy)."""
+    kpts = _detect_gpu(args, im_rgb, detector, device)
+    gray = torch.as_tensor(np.ascontiguousarray(im_gray), device=device)
+    with torch.inference_mode():
+        patches = ops.extract_patches(gray, kpts[:, :2], float(args.s_mult))
+        descs = descriptor(patches)
+    return kpts[:, :2].double().cpu().numpy(), descs.cpu().numpy()
+
+
+def extract_matches(args, im_rgb1, im_gray1, im_rgb2, im_gray2, detector, descriptor, device):
+    """demo_match.py:97-112: -> (points1 [m,2], points2 [m,2]) of the mutual ratio-test matches (th 0.99)."""
+    kpts1, desc1 = extract_features(args, im_rgb1, im_gray1, detector, descriptor, device)
+    kpts2, desc2 = extract_features(args, im_rgb2, im_gray2, detector, descriptor, device)
+    with torch.inference_mode():
+        _, match_ids = ops.match_smnn(torch.from_numpy(desc1).to(device), torch.from_numpy(desc2).to(device), 0.99)
+    match_ids = match_ids.cpu().numpy()
+    return kpts1[match_ids[:, 0], :2], kpts2[match_ids[:, 1], :2]

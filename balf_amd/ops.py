@@ -102,3 +102,54 @@ def profile_end():
     cnt = (C.c_int * n)()
     check(l.balf_profile_end(ms, cnt), "balf_profile_end")
     return {l.balf_profile_slot_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n) if cnt[i]}
+
+
+def extract_patches(gray_u8: torch.Tensor, xy: torch.Tensor, scale: float) -> torch.Tensor:
+    """uint8 gray image [H,W] + keypoints [N,2] (x, y) -> patches [N,1,32,32] fp32 in [0,1]: what
+    ``K.feature.extract_patches_from_pyramid(gray/255, laf_from_center_scale_ori(kp, scale, 0), PS=32)`` returns in
+    /root/reference/demo/demo_match.py:62-70 (balf_extract_patches in include/balf_hip.h)."""
+    require_gpu_tensor(gray_u8, "gray_u8")
+    if not xy.is_cuda:
+        raise BalfHipError("xy must live on the GPU")
+    if gray_u8.dtype != torch.uint8 or gray_u8.dim() != 2:
+        raise BalfHipError("gray_u8 must be a [H,W] uint8 tensor")
+    if xy.dim() != 2 or xy.shape[1] != 2:
+        raise BalfHipError("xy must be [N,2]")
+    xy = xy.contiguous().float()
+    n = xy.shape[0]
+    h, w = gray_u8.shape
+    dev = gray_u8.device
+    out = torch.empty((n, 1, 32, 32), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    nbytes = lib().balf_extract_patches_workspace_bytes(h, w, float(scale))
+    ws = _workspace("patches", dev, nbytes)
+    with torch.cuda.device(dev):
+        check(lib().balf_extract_patches(gray_u8.data_ptr(), h, w, xy.data_ptr(), n, float(scale), out.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), current_stream_ptr(dev)), "balf_extract_patches")
+    return out
+
+
+def match_smnn(desc1: torch.Tensor, desc2: torch.Tensor, th: float = 0.8) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``kornia.feature.match_smnn(desc1, desc2, th)`` (/root/reference/demo/demo_match.py:104-110): returns
+    (dists [M,1] fp32, idxs [M,2] int64), mutual ratio-test matches sorted by the index in ``desc1``."""
+    require_gpu_tensor(desc1, "desc1")
+    require_gpu_tensor(desc2, "desc2")
+    if desc1.dim() != 2 or desc2.dim() != 2 or desc1.shape[1] != 128 or desc2.shape[1] != 128:
+        raise BalfHipError("descriptors must be [N,128]")
+    desc1, desc2 = desc1.float().contiguous(), desc2.float().contiguous()
+    n1, n2 = desc1.shape[0], desc2.shape[0]
+    dev = desc1.device
+    if n1 == 0 or n2 == 0:
+        return (torch.zeros((0, 1), dtype=torch.float32, device=dev), torch.zeros((0, 2), dtype=torch.int64, device=dev))
+    cap = min(n1, n2)
+    idx = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    dist = torch.empty((cap,), dtype=torch.float32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = _workspace("match", dev, lib().balf_match_smnn_workspace_bytes(n1, n2))
+    with torch.cuda.device(dev):
+        check(lib().balf_match_smnn(desc1.data_ptr(), n1, desc2.data_ptr(), n2, float(th), idx.data_ptr(),
+                                    dist.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    current_stream_ptr(dev)), "balf_match_smnn")
+    m = int(count.item())
+    return dist[:m].view(-1, 1), idx[:m].long()

@@ -78,3 +78,50 @@ def gray_to_rgb_norm(gray_u8: np.ndarray) -> np.ndarray:
     (/root/reference/demo/demo_match.py:21-22 with F4's channel replication)."""
     g = gray_u8.astype(np.float64) / 255.0
     return np.stack([g, g, g], axis=-1)
+
+
+# ----------------------------------------------------------------------------------------
+# HardNet descriptor (demo path; /root/reference/third_party/hardnet/hardnet_pytorch.py:31-55)
+# ----------------------------------------------------------------------------------------
+# (features index of the conv, out channels, in channels, kernel); BatchNorm2d(affine=False) sits at index + 1
+HARDNET_CONVS = ((0, 32, 1, 3), (3, 32, 32, 3), (6, 64, 32, 3), (9, 64, 64, 3), (12, 128, 64, 3),
+                 (15, 128, 128, 3), (19, 128, 128, 8))
+
+
+def hardnet_state_entries():
+    out = []
+    for idx, co, ci, k in HARDNET_CONVS:
+        out.append((f"features.{idx}.weight", (co, ci, k, k), "float32"))
+        out.append((f"features.{idx + 1}.running_mean", (co,), "float32"))
+        out.append((f"features.{idx + 1}.running_var", (co,), "float32"))
+        out.append((f"features.{idx + 1}.num_batches_tracked", (), "int64"))
+    return out
+
+
+def synthetic_hardnet_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded HardNet weights (He-scaled convs, randomised BatchNorm running statistics), in the
+    reference's state-dict order.  No pretrained HardNet++ checkpoint exists offline."""
+    sd: Dict[str, torch.Tensor] = {}
+    for i, (name, shape, dtype) in enumerate(hardnet_state_entries()):
+        rng = np.random.Generator(np.random.PCG64([int(seed), 7000 + i]))
+        if dtype == "int64":
+            sd[name] = torch.tensor(0, dtype=torch.int64)
+            continue
+        if name.endswith("weight"):
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+        elif name.endswith("running_mean"):
+            v = 0.2 * rng.standard_normal(shape)
+        else:
+            v = rng.uniform(0.5, 1.5, shape)
+        sd[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return sd
+
+
+def synthetic_patches(n: int, seed: int = 0) -> torch.Tensor:
+    """[n,1,32,32] float32 patches in [0,1] with some spatial structure (smoothed noise + a ramp)."""
+    rng = np.random.default_rng(4321 + int(seed))
+    g = rng.random((n, 36, 36), dtype=np.float32)
+    sm = (g[:, :-4, :-4] + g[:, 2:-2, 2:-2] + g[:, 4:, 4:] + g[:, :-4, 4:] + g[:, 4:, :-4]) / 5.0
+    ramp = np.linspace(0.0, 0.3, 32, dtype=np.float32)[None, :, None] * rng.random((n, 1, 1), dtype=np.float32)
+    return torch.from_numpy(np.clip(sm + ramp, 0.0, 1.0).astype(np.float32)).unsqueeze(1)

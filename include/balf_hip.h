@@ -119,6 +119,40 @@ int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int crop_y, in
                     float *score_dev, float *xy_dev, int32_t *count_dev, int32_t *total_dev, void *workspace_dev,
                     size_t workspace_bytes, void *stream);
 
+/* ---- HardNet patch descriptor of the demo path ----------------------------------------
+ * Replaces HardNet.load_state_dict / HardNet.forward, third_party/hardnet/hardnet_pytorch.py:31-72, as called by
+ * demo/demo_match.py:72-93,131-134.  The 21 floating-point state tensors in state_dict() order are, per
+ * convolution i in features.{0,3,6,9,12,15,19}: weight [Cout,Cin,k,k], then the following BatchNorm's running_mean
+ * and running_var (num_batches_tracked is skipped).  balf_hardnet_pack_weights runs on the HOST (BatchNorm folded,
+ * split-f16 MFMA fragment order); the caller copies the blob to the device.
+ * balf_hardnet_forward: patches_dev [N,32,32] fp32 (the [N,1,32,32] tensor HardNet.forward takes) ->
+ * desc_dev [N,128] fp32, L2-normalised.  Contractions run on v_mfma_f32_16x16x32_f16 with split (hi+lo) operands,
+ * fp32 accumulation: descriptors agree with the fp32 reference to ~1e-5. */
+int balf_hardnet_num_state_tensors(void);
+const char *balf_hardnet_state_tensor_name(int i);
+size_t balf_hardnet_state_tensor_numel(int i);
+size_t balf_hardnet_packed_weights_bytes(void);
+int balf_hardnet_pack_weights(const float *const *tensors, int n_tensors, void *packed_host, size_t packed_bytes);
+size_t balf_hardnet_workspace_bytes(int n_patches);
+int balf_hardnet_forward(const void *packed_dev, const float *patches_dev, int n_patches, float *desc_dev,
+                         void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* ---- patch extraction and descriptor matching of the demo path -------------------------
+ * balf_extract_patches replaces kornia.feature.laf_from_center_scale_ori + extract_patches_from_pyramid(PS=32) as
+ * called by demo/demo_match.py:62-70: gray_dev uint8 [H,W]; xy_dev [N,2] keypoint (x, y) in pixels; `scale` = the
+ * LAF scale (args.s_mult) shared by all keypoints; patches_dev [N,32,32] fp32 in [0,1].
+ * balf_match_smnn replaces kornia.feature.match_smnn(desc1, desc2, th) (demo_match.py:104-110): descriptors
+ * [n,128] fp32; outputs idx_dev [min(n1,n2),2] (index in desc1, index in desc2; -1 padded, sorted by the first),
+ * dist_dev [min(n1,n2)] (max of the two nearest/second-nearest distance ratios), count_dev [1].
+ * kornia is a third-party dependency that is absent offline: both follow its published algorithm and are checked
+ * against this repo's restatement only (parity unpinned). */
+size_t balf_extract_patches_workspace_bytes(int H, int W, float scale);
+int balf_extract_patches(const unsigned char *gray_dev, int H, int W, const float *xy_dev, int n_points, float scale,
+                         float *patches_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+size_t balf_match_smnn_workspace_bytes(int n1, int n2);
+int balf_match_smnn(const float *desc1_dev, int n1, const float *desc2_dev, int n2, float th, int32_t *idx_dev,
+                    float *dist_dev, int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* ---- measurement aid (not part of the data path) ---------------------------------------------
  * Between balf_profile_begin() and balf_profile_end() every kernel launch of the library is bracketed
  * by a hipEvent pair on its launch stream.  balf_profile_end() waits for those events and returns,

@@ -260,3 +260,108 @@ def soft_argmax_refine(heatmap: np.ndarray, idx: np.ndarray, patch: int) -> np.n
         gx, gy = np.meshgrid(np.arange(patch), np.arange(patch))
         out[n] = (x + (pt * gx).sum() / s - pad, y + (pt * gy).sum() / s - pad)
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# demo descriptor / matching path
+# ----------------------------------------------------------------------------------------
+_HARDNET_CONVS = ((0, 1, 1), (3, 1, 1), (6, 2, 1), (9, 1, 1), (12, 2, 1), (15, 1, 1), (19, 1, 0))   # (index, stride, padding)
+
+
+def hardnet_forward(sd: Dict[str, torch.Tensor], patches: torch.Tensor, taps: dict = None) -> torch.Tensor:
+    """HardNet descriptor of [N,1,32,32] patches -> [N,128], L2-normalised.
+    /root/reference/third_party/hardnet/hardnet_pytorch.py:58-72: per-patch (mean, unbiased std + 1e-7)
+    normalisation, 6 x [conv3x3 (no bias) -> BatchNorm(eval, affine=False, eps 1e-5) -> ReLU], Dropout (identity in
+    eval), conv8x8 -> BatchNorm, then x / sqrt(sum x^2 + 1e-10) (:6-15).  Pinned by tests/golden/hardnet.npz."""
+    x = patches.to(sd["features.0.weight"].dtype)
+    flat = x.reshape(x.shape[0], -1)
+    mp = flat.mean(dim=1)
+    sp = flat.std(dim=1) + 1e-7
+    x = (x - mp.view(-1, 1, 1, 1)) / sp.view(-1, 1, 1, 1)
+    for j, (idx, stride, pad) in enumerate(_HARDNET_CONVS):
+        x = F.conv2d(x, sd[f"features.{idx}.weight"], None, stride=stride, padding=pad)
+        mean, var = sd[f"features.{idx + 1}.running_mean"], sd[f"features.{idx + 1}.running_var"]
+        x = (x - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5)
+        if j < 6:
+            x = torch.relu(x)
+        if taps is not None:
+            taps[j] = x
+    x = x.reshape(x.shape[0], -1)
+    return x / torch.sqrt((x * x).sum(dim=1) + 1e-10).unsqueeze(-1)
+
+
+def pyrdown(img: torch.Tensor) -> torch.Tensor:
+    """kornia.geometry.transform.pyrdown (PARITY UNPINNED: kornia is not installed offline): 5x5 binomial blur
+    ([1,4,6,4,1] x [1,4,6,4,1] / 256, reflect border) followed by bilinear resampling to (H//2, W//2),
+    align_corners=False.  img [B,C,H,W]."""
+    k1 = torch.tensor([1.0, 4.0, 6.0, 4.0, 1.0], dtype=img.dtype)
+    k = (k1[:, None] * k1[None, :] / 256.0).view(1, 1, 5, 5)
+    b, c, h, w = img.shape
+    xp = F.pad(img, (2, 2, 2, 2), mode="reflect")
+    blur = F.conv2d(xp.reshape(b * c, 1, h + 4, w + 4), k).reshape(b, c, h, w)
+    return F.interpolate(blur, size=(h // 2, w // 2), mode="bilinear", align_corners=False)
+
+
+def extract_patches(gray: torch.Tensor, xy: torch.Tensor, scale: float, ps: int = 32) -> torch.Tensor:
+    """What demo_match.extract_features:62-70 gets from kornia: laf_from_center_scale_ori(xy, scale, 0) ->
+    extract_patches_from_pyramid(img, laf, PS).  PARITY UNPINNED (kornia absent); restated from kornia's
+    published source (kornia/feature/laf.py, 0.6-0.7 series):
+      * pyramid level = clamp(floor(log2(2 * scale / PS)), 0, max(0, min(H, W) // PS - 1)), level l image =
+        pyrdown applied l times (the loop also stops once a level is smaller than PS);
+      * LAF [[s,0,x],[0,s,y]] normalised by (min(H,W)-1 | W-1 | H-1) of the full image and de-normalised with the
+        level's size; sampling grid = affine_grid(LAF, PS x PS, align_corners=False), i.e. base coordinates
+        (2i + 1)/PS - 1, mapped to [-1,1] by 2 g / (w_l - 1) - 1 and sampled with
+        grid_sample(bilinear, padding_mode='border', align_corners=False).
+    gray [H,W] float in [0,1]; xy [N,2] (x, y) pixel coordinates.  Returns [N,1,ps,ps]."""
+    img = gray.view(1, 1, *gray.shape).to(torch.float32)
+    n = xy.shape[0]
+    h0, w0 = gray.shape
+    max_level = min(h0, w0) // ps
+    level = int(np.clip(np.floor(np.log2(2.0 * np.sqrt(scale * scale + 1e-10) / ps)), 0.0, max(0, max_level - 1)))
+    cur = img
+    for _ in range(level):
+        if min(cur.shape[2], cur.shape[3]) < ps:
+            break
+        cur = pyrdown(cur)
+    hl, wl = cur.shape[2], cur.shape[3]
+    ms0, msl = float(min(h0 - 1, w0 - 1)), float(min(hl - 1, wl - 1))
+    s_l = scale / ms0 * msl
+    x_l = xy[:, 0].to(torch.float32) / float(w0 - 1) * float(wl - 1)
+    y_l = xy[:, 1].to(torch.float32) / float(h0 - 1) * float(hl - 1)
+    base = (2.0 * torch.arange(ps, dtype=torch.float32) + 1.0) / ps - 1.0
+    gx = s_l * base.view(1, 1, ps) + x_l.view(n, 1, 1)                  # [n,1,ps]
+    gy = s_l * base.view(1, ps, 1) + y_l.view(n, 1, 1)                  # [n,ps,1]
+    grid = torch.stack([(2.0 * gx / float(wl - 1) - 1.0).expand(n, ps, ps),
+                        (2.0 * gy / float(hl - 1) - 1.0).expand(n, ps, ps)], dim=-1)
+    return F.grid_sample(cur.expand(n, 1, hl, wl), grid, mode="bilinear", padding_mode="border", align_corners=False)
+
+
+def match_snn(d1: torch.Tensor, d2: torch.Tensor, th: float):
+    """kornia.feature.match_snn restated (PARITY UNPINNED): Euclidean distance matrix, the two smallest per row,
+    keep rows with d_first / d_second <= th.  Returns (ratio [M], idx [M,2])."""
+    if d2.shape[0] < 2 or d1.shape[0] == 0:
+        return torch.zeros(0, dtype=d1.dtype), torch.zeros(0, 2, dtype=torch.int64)
+    dm = torch.cdist(d1.double(), d2.double()).to(d1.dtype)
+    vals, idx = torch.topk(dm, 2, dim=1, largest=False)
+    ratio = vals[:, 0] / vals[:, 1]
+    mask = ratio <= th
+    i1 = torch.arange(d1.shape[0])[mask]
+    return ratio[mask], torch.stack([i1, idx[:, 0][mask]], dim=1)
+
+
+def match_smnn(d1: torch.Tensor, d2: torch.Tensor, th: float = 0.99):
+    """kornia.feature.match_smnn restated (demo_match.py:105-107; PARITY UNPINNED): ratio-test matches in both
+    directions, keep the mutual ones; distance = max of the two ratios; sorted by the index in d1."""
+    r1, m1 = match_snn(d1, d2, th)
+    r2, m2 = match_snn(d2, d1, th)
+    if len(r1) == 0 or len(r2) == 0:
+        return torch.zeros(0, dtype=d1.dtype), torch.zeros(0, 2, dtype=torch.int64)
+    back = {int(j): (int(i), float(r)) for (j, i), r in zip(m2.tolist(), r2.tolist())}    # d2 index -> (d1 index, ratio)
+    out_i, out_r = [], []
+    for (i, j), r in zip(m1.tolist(), r1.tolist()):
+        if j in back and back[j][0] == i:
+            out_i.append((i, j))
+            out_r.append(max(r, back[j][1]))
+    if not out_i:
+        return torch.zeros(0, dtype=d1.dtype), torch.zeros(0, 2, dtype=torch.int64)
+    return torch.tensor(out_r, dtype=d1.dtype), torch.tensor(out_i, dtype=torch.int64)

@@ -93,3 +93,9 @@ GREEDY_CASES = {
     "g_ramp":          dict(h=80, w=200, seed=26, kind="ramp", border=0, conf=0.001, nms=8),
     "g_vga_blobs":     dict(h=480, w=640, seed=27, kind="blobs", border=15, conf=0.001, nms=15),
 }
+
+
+# HardNet descriptor cases: name -> (number of patches, patch seed); weights = synthetic_hardnet_state_dict(HARDNET_SEED)
+HARDNET_SEED = 515
+HARDNET_CASES = {"n5": (5, 1), "n70": (70, 2)}
+HARDNET_TAP_CASE = "n5"          # per-layer activations of patch 0, every 4th channel

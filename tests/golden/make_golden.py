@@ -13,6 +13,8 @@ What is recorded is data only -- inputs are regenerated from seeds, outputs are 
   nms_topk.npz        remove_borders/apply_nms/find_index_higher_scores results on synthetic
                       score maps (random, tie-heavy, all-zero, sparse, even window sizes)
   geometry.json       pad/crop shapes+offsets, state-dict table, checkpoint-loader behaviour
+  hardnet.npz         descriptors (+ per-layer activations of one patch) of the reference's HardNet class with the
+                      seeded synthetic weights, on synthetic patches
 """
 import json
 import os
@@ -31,6 +33,7 @@ warnings.filterwarnings("ignore")
 
 from balf.model import get_model as ref_get_model          # noqa: E402  (reference)
 from balf.utils import test_utils as RT                     # noqa: E402  (reference)
+from third_party.hardnet.hardnet_pytorch import HardNet     # noqa: E402  (reference)
 
 from balf_amd.utils import synth                            # noqa: E402
 from tests.golden import cases                              # noqa: E402
@@ -128,6 +131,28 @@ def main():
             gk[name + ".idx"] = (pts[:, 1].astype(np.int64) * score.shape[1] + pts[:, 0].astype(np.int64)).astype(np.int32)
             gk[name + ".score"] = pts[:, 3].astype(np.float32)      # emitted sorted by confidence, descending
     np.savez_compressed(os.path.join(HERE, "greedy_nms.npz"), **gk)
+
+    # ---------------- HardNet descriptor (demo path) ----------------
+    hn = HardNet().eval()
+    hsd = synth.synthetic_hardnet_state_dict(cases.HARDNET_SEED)
+    assert list(hsd.keys()) == list(hn.state_dict().keys())
+    hn.load_state_dict(hsd)
+    hk = {}
+    for name, (n, seed) in cases.HARDNET_CASES.items():
+        x = synth.synthetic_patches(n, seed)
+        acts = []
+        hooks = []
+        if name == cases.HARDNET_TAP_CASE:
+            for i in (2, 5, 8, 11, 14, 17, 20):          # the ReLU after each conv+BN, and the last BN
+                hooks.append(hn.features[i].register_forward_hook(lambda mod, inp, out: acts.append(out.detach().numpy().copy())))
+        with torch.inference_mode():
+            hk[name + ".desc"] = hn(x).numpy()
+        for h_ in hooks:
+            h_.remove()
+        for j, a in enumerate(acts):
+            hk[f"{name}.act{j}"] = a[0, ::4].copy()
+    hk["state_keys"] = np.array(list(hn.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, "hardnet.npz"), **hk)
 
     # ---------------- geometry, state-dict table, loader behaviour ----------------
     geo = {"pad": {}, "state": [], "loader": {}}

@@ -140,3 +140,40 @@ def test_shard_range_partitions_the_batch():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+# ---------------- demo path: HardNet container, demo_match mirror ----------------
+def test_hardnet_container_matches_reference_state_dict():
+    import numpy as np
+    from balf_amd.third_party.hardnet.hardnet_pytorch import HardNet
+    from balf_amd.utils import synth
+    keys = list(np.load(os.path.join(os.path.dirname(__file__), "golden", "hardnet.npz"))["state_keys"])
+    m = HardNet()
+    assert list(m.state_dict().keys()) == keys                      # recorded from the reference's class
+    sd = synth.synthetic_hardnet_state_dict(1)
+    m.load_state_dict({"state_dict": sd}["state_dict"])             # demo_match.py:132-133
+    assert all(tuple(m.state_dict()[k].shape) == tuple(v.shape) for k, v in sd.items())
+
+
+def test_hardnet_has_no_cpu_path():
+    from balf_amd._lib import BalfHipError
+    from balf_amd.third_party.hardnet.hardnet_pytorch import HardNet
+    m = HardNet().eval()
+    with pytest.raises(BalfHipError):
+        m(torch.zeros(2, 1, 32, 32))
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 3, 32, 32))
+    with pytest.raises(BalfHipError):
+        HardNet().train()(torch.zeros(2, 1, 32, 32))
+
+
+def test_demo_match_mirror_signatures():
+    import inspect
+    from balf_amd.demo import demo_match
+    assert list(inspect.signature(demo_match.detect).parameters) == ["args", "im", "detector", "device"]
+    assert list(inspect.signature(demo_match.extract_features).parameters) == [
+        "args", "im_rgb", "im_gray", "detector", "descriptor", "device"]
+    assert list(inspect.signature(demo_match.extract_matches).parameters) == [
+        "args", "im_rgb1", "im_gray1", "im_rgb2", "im_gray2", "detector", "descriptor", "device"]
+    a = demo_match.DEFAULT_ARGS          # /root/reference/balf/configs/config.py:44-59
+    assert (a.border_size, a.nms_size, a.num_features, a.s_mult, a.patch_size) == (15, 15, 2048, 60, 4)

@@ -119,3 +119,44 @@ def test_greedy_nms_cases(name):
     idx, sc = O.greedy_nms(rb, spec["conf"], spec["nms"])
     assert np.array_equal(idx.astype(np.int32), f[name + ".idx"])
     assert np.array_equal(sc.astype(np.float32).view(np.uint32), f[name + ".score"].view(np.uint32))
+
+
+# ---------------- HardNet descriptor ----------------
+def test_hardnet_oracle_matches_reference_goldens():
+    """O.hardnet_forward against descriptors (and per-layer activations) recorded from the reference's own
+    HardNet class (third_party/hardnet/hardnet_pytorch.py) with the seeded synthetic weights."""
+    g = np.load(os.path.join(G, "hardnet.npz"))
+    sd = synth.synthetic_hardnet_state_dict(cases.HARDNET_SEED)
+    assert list(g["state_keys"]) == list(sd.keys())
+    for name, (n, seed) in cases.HARDNET_CASES.items():
+        taps = {}
+        d = O.hardnet_forward(sd, synth.synthetic_patches(n, seed), taps).numpy()
+        assert np.abs(d - g[name + ".desc"]).max() < 1e-6
+        if name == cases.HARDNET_TAP_CASE:
+            for j in range(7):
+                assert np.abs(taps[j][0, ::4].numpy() - g[f"{name}.act{j}"]).max() < 2e-5
+
+
+def test_match_smnn_oracle_hand_case():
+    """Mutual ratio test on a case small enough to check by hand."""
+    e = np.eye(128, dtype=np.float32)
+    d1 = torch.from_numpy(np.stack([e[0], e[1], e[2]]))
+    d2 = torch.from_numpy(np.stack([e[1] * 0.9 + e[5] * 0.1, e[0], e[7], e[8]]))
+    dist, idx = O.match_smnn(d1, d2, 0.9)
+    # d1[0] <-> d2[1] (distance 0, ratio 0); d1[1] <-> d2[0]: forward 0.1414/1.4142 = 0.1, backward
+    # 0.1414/sqrt(1.82) = 0.10483 -> max; d1[2] has no clear neighbour
+    assert idx.tolist() == [[0, 1], [1, 0]]
+    assert abs(float(dist[0])) < 1e-6 and abs(float(dist[1]) - (0.02 / 1.82) ** 0.5) < 1e-6
+    assert O.match_smnn(d1, d2[:1], 0.9)[1].shape == (0, 2)          # fewer than two candidates: no matches
+
+
+def test_extract_patches_oracle_identity_scale():
+    """With scale = PS/2 at pyramid level 0 and a keypoint on the pixel grid, the 32 sampling positions are
+    x + (2i + 1)/2 - 16 scaled by W/(W-1): the centre sample pair straddles the keypoint."""
+    h, w = 96, 128
+    img = torch.arange(h * w, dtype=torch.float32).view(h, w) / (h * w)
+    p = O.extract_patches(img, torch.tensor([[64.0, 48.0]]), 16.0)
+    assert p.shape == (1, 1, 32, 32)
+    mid = 0.25 * (p[0, 0, 15, 15] + p[0, 0, 15, 16] + p[0, 0, 16, 15] + p[0, 0, 16, 16])
+    gx, gy = 64.0 * w / (w - 1) - 0.5, 48.0 * h / (h - 1) - 0.5           # where kornia's mixed conventions land
+    assert abs(float(mid) - (gy * w + gx) / (h * w)) < 1e-4
