@@ -47,6 +47,10 @@ PROTOTYPES = {
     "balf_extract_patches": (_i, [_vp, _i, _i, _fp, _i, C.c_float, _fp, _vp, _sz, _vp]),
     "balf_match_smnn_workspace_bytes": (_sz, [_i, _i]),
     "balf_match_smnn": (_i, [_fp, _i, _fp, _i, C.c_float, _vp, _fp, _vp, _vp, _sz, _vp]),
+    "balf_repeatability_workspace_bytes": (_sz, [_i, _i, _i]),
+    "balf_repeatability": (_i, [_vp, _i, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_double, _i, _vp, _vp, _vp, _vp,
+                               _vp, _sz, _vp]),
+    "balf_apply_homography": (_i, [_vp, _i, _vp, _vp, _vp]),
     "balf_profile_num_slots": (_i, []),
     "balf_profile_slot_name": (C.c_char_p, [_i]),
     "balf_profile_begin": (_i, []),

@@ -22,6 +22,7 @@
 // A workgroup is 4 waves; a wave owns 2 output-channel tiles x 4 pixel tiles (8 accumulator tiles).  Weights are
 // read from global memory (L2-resident, <= 576 KiB per layer) in A-fragment order, one K-step ahead.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -202,19 +203,30 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
         }
     } else {
         // ---- copy the input band (both planes) into the swizzled LDS image, zero frame included ----
+        // All global loads are issued before the first LDS write, so a workgroup pays one HBM round trip.
         const _Float16 *in = static_cast<const _Float16 *>(a.in) + (size_t)patch * 2 * HIN * HIN * CIN;
-        constexpr int TOTAL = 2 * Cfg::NQ * CH;
-#pragma unroll 4
-        for (int i = tid; i < TOTAL; i += 256) {
+        constexpr int TOTAL = 2 * Cfg::NQ * CH, ITERS = (TOTAL + 255) / 256;
+        h8 stage[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + 256 * it;
             const int plane = i / (Cfg::NQ * CH);
             const int rem = i - plane * (Cfg::NQ * CH);
             const int q = rem / CH, c = rem - q * CH;
             const int iy = q / WP, ixp = q - iy * WP;
             const int y = r_in0 + iy, x = ixp - 1;
-            h8 v = zero8();
-            if (y >= 0 && y < HIN && x >= 0 && x < HIN)
-                v = *reinterpret_cast<const h8 *>(in + ((size_t)(plane * HIN + y) * HIN + x) * CIN + c * 8);
-            *reinterpret_cast<h8 *>(act + plane * Cfg::PLANE_BYTES + q * (CIN * 2) + ((c ^ swz<CH>(q)) << 4)) = v;
+            stage[it] = zero8();
+            if (i < TOTAL && y >= 0 && y < HIN && x >= 0 && x < HIN)
+                stage[it] = *reinterpret_cast<const h8 *>(in + ((size_t)(plane * HIN + y) * HIN + x) * CIN + c * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + 256 * it;
+            const int plane = i / (Cfg::NQ * CH);
+            const int rem = i - plane * (Cfg::NQ * CH);
+            const int q = rem / CH, c = rem - q * CH;
+            if (i < TOTAL)
+                *reinterpret_cast<h8 *>(act + plane * Cfg::PLANE_BYTES + q * (CIN * 2) + ((c ^ swz<CH>(q)) << 4)) = stage[it];
         }
     }
     __syncthreads();
@@ -243,47 +255,41 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
             dst[m].lo = *reinterpret_cast<const h8 *>(p + 1024);
         }
     };
-    HL acur[WM];
-    load_a(0, acur);
-    int ks = 0;
-#pragma unroll 1
-    for (int ky = 0; ky < 3; ++ky) {
+    auto load_b = [&](int ks, HL (&dst)[WN]) {          // ks is a compile-time constant after unrolling
+        const int tap = ks / KPT, kk = ks - tap * KPT;
+        const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            int qb[WN], sw[WN];
-#pragma unroll
-            for (int t = 0; t < WN; ++t) {
-                const int q = q0[t] + ky * WP + kx;
-                qb[t] = q * (CIN * 2);
-                sw[t] = swz<CH>(q);
-            }
-#pragma unroll
-            for (int kk = 0; kk < KPT; ++kk, ++ks) {
-                HL anext[WM];
-                load_a(ks + 1 < Cfg::KS ? ks + 1 : ks, anext);
-                HL b[WN];
-#pragma unroll
-                for (int t = 0; t < WN; ++t) {
-                    const int off = qb[t] + (((kk * 4 + g) ^ sw[t]) << 4);
-                    b[t].hi = *reinterpret_cast<const h8 *>(act + off);
-                    b[t].lo = *reinterpret_cast<const h8 *>(act + Cfg::PLANE_BYTES + off);
-                }
-#pragma unroll
-                for (int m = 0; m < WM; ++m)
-#pragma unroll
-                    for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(acur[m].lo, b[t].hi, acc[m][t]);
-#pragma unroll
-                for (int m = 0; m < WM; ++m)
-#pragma unroll
-                    for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(acur[m].hi, b[t].lo, acc[m][t]);
-#pragma unroll
-                for (int m = 0; m < WM; ++m)
-#pragma unroll
-                    for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(acur[m].hi, b[t].hi, acc[m][t]);
-#pragma unroll
-                for (int m = 0; m < WM; ++m) acur[m] = anext[m];
-            }
+        for (int t = 0; t < WN; ++t) {
+            const int q = q0[t] + ky * WP + kx;
+            const int off = q * (CIN * 2) + (((kk * 4 + g) ^ swz<CH>(q)) << 4);
+            dst[t].hi = *reinterpret_cast<const h8 *>(act + off);
+            dst[t].lo = *reinterpret_cast<const h8 *>(act + Cfg::PLANE_BYTES + off);
         }
+    };
+    HL abuf[2][WM], bbuf[2][WN];
+    load_a(0, abuf[0]);
+    load_b(0, bbuf[0]);
+#pragma unroll
+    for (int ks = 0; ks < Cfg::KS; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < Cfg::KS) {
+            load_a(ks + 1, abuf[nxt]);
+            load_b(ks + 1, bbuf[nxt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch distance at exactly one K-step
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[cur][m].lo, bbuf[cur][t].hi, acc[m][t]);
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[cur][m].hi, bbuf[cur][t].lo, acc[m][t]);
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[cur][m].hi, bbuf[cur][t].hi, acc[m][t]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- bias (folded BatchNorm) + ReLU, split, store both planes ----
@@ -313,7 +319,9 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
 }
 
 // The last layer: out[co][patch] = sum_k W7[co][k] a6[patch][k], k = (y*8 + x)*128 + c -- exactly the order a6 is
-// stored in.  64 patches per workgroup; wave w owns channel tiles 2w, 2w+1 for all four patch tiles.
+// stored in.  128 patches per workgroup; a wave owns all 8 channel tiles of its 32 patches, so the L2 norm never
+// leaves the wave.  The weights (4 MiB, shared by every workgroup) stream through a double-buffered LDS stage of
+// two K-steps; the B operand comes straight from HBM one stage ahead.
 struct FcArgs {
     const _Float16 *in;      // [N][2][8192]
     float *desc;             // [N][128]
@@ -322,12 +330,14 @@ struct FcArgs {
     int n_patches;
 };
 
+constexpr int kFcStageKs = 2, kFcStageBytes = kFcStageKs * 8 * 2048, kFcLds = 2 * kFcStageBytes;
+
 __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
-    constexpr int WM = 2, WN = 4, MT = 8, KS = kFcK / 32;
-    __shared__ float ssq[4][64];
+    constexpr int MT = 8, WN = 2, KS = kFcK / 32, NST = KS / kFcStageKs;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int p0 = blockIdx.x * 64;
+    const int p0 = blockIdx.x * 128 + wave * 32;
     const _Float16 *bp[WN];
 #pragma unroll
     for (int t = 0; t < WN; ++t) {
@@ -335,38 +345,70 @@ __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
         p = p < a.n_patches ? p : a.n_patches - 1;
         bp[t] = a.in + (size_t)p * 2 * kFcK + g * 8;
     }
-    f4 acc[WM][WN];
+    f4 acc[MT][WN];
 #pragma unroll
-    for (int m = 0; m < WM; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < WN; ++t) acc[m][t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    const char *wl = a.w + (size_t)(wave * WM) * 2048 + lane * 16;
-#pragma unroll 2
-    for (int ks = 0; ks < KS; ++ks) {
-        HL wa[WM], b[WN];
+
+    constexpr int CP = kFcStageBytes / (256 * 16);          // 16-byte pieces per thread per stage
+    h8 wreg[CP];
+    HL breg[kFcStageKs][WN];
+    auto fetch_w = [&](int st) {
 #pragma unroll
-        for (int m = 0; m < WM; ++m) {
-            const char *p = wl + ((size_t)ks * MT + m) * 2048;
-            wa[m].hi = *reinterpret_cast<const h8 *>(p);
-            wa[m].lo = *reinterpret_cast<const h8 *>(p + 1024);
-        }
+        for (int c = 0; c < CP; ++c)
+            wreg[c] = *reinterpret_cast<const h8 *>(a.w + (size_t)st * kFcStageBytes + (size_t)(c * 256 + tid) * 16);
+    };
+    auto put_w = [&](int buf) {
 #pragma unroll
-        for (int t = 0; t < WN; ++t) {
-            b[t].hi = *reinterpret_cast<const h8 *>(bp[t] + ks * 32);
-            b[t].lo = *reinterpret_cast<const h8 *>(bp[t] + kFcK + ks * 32);
-        }
+        for (int c = 0; c < CP; ++c)
+            *reinterpret_cast<h8 *>(smem + buf * kFcStageBytes + (c * 256 + tid) * 16) = wreg[c];
+    };
+    auto fetch_b = [&](int st) {
 #pragma unroll
-        for (int m = 0; m < WM; ++m)
+        for (int k2 = 0; k2 < kFcStageKs; ++k2)
 #pragma unroll
-            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16x3(wa[m], b[t], acc[m][t]);
+            for (int t = 0; t < WN; ++t) {
+                breg[k2][t].hi = *reinterpret_cast<const h8 *>(bp[t] + (st * kFcStageKs + k2) * 32);
+                breg[k2][t].lo = *reinterpret_cast<const h8 *>(bp[t] + kFcK + (st * kFcStageKs + k2) * 32);
+            }
+    };
+    fetch_w(0);
+    fetch_b(0);
+    put_w(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < NST; ++st) {
+        const int buf = st & 1;
+        HL bcur[kFcStageKs][WN];
+#pragma unroll
+        for (int k2 = 0; k2 < kFcStageKs; ++k2)
+#pragma unroll
+            for (int t = 0; t < WN; ++t) bcur[k2][t] = breg[k2][t];
+        const int nst = st + 1 < NST ? st + 1 : st;
+        fetch_w(nst);
+        fetch_b(nst);
+#pragma unroll
+        for (int k2 = 0; k2 < kFcStageKs; ++k2)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                HL wa;
+                const char *p = smem + buf * kFcStageBytes + ((k2 * MT + m) * 2048) + lane * 16;
+                wa.hi = *reinterpret_cast<const h8 *>(p);
+                wa.lo = *reinterpret_cast<const h8 *>(p + 1024);
+#pragma unroll
+                for (int t = 0; t < WN; ++t) acc[m][t] = mfma16x3(wa, bcur[k2][t], acc[m][t]);
+            }
+        put_w(buf ^ 1);
+        __syncthreads();
     }
     // BatchNorm bias, then x / sqrt(sum x^2 + 1e-10) over the 128 channels of each patch (hardnet_pytorch.py:11-15)
     float part[WN];
 #pragma unroll
     for (int t = 0; t < WN; ++t) part[t] = 0.0f;
 #pragma unroll
-    for (int m = 0; m < WM; ++m) {
-        const f4 bb = *reinterpret_cast<const f4 *>(a.bias + 16 * (wave * WM + m) + 4 * g);
+    for (int m = 0; m < MT; ++m) {
+        const f4 bb = *reinterpret_cast<const f4 *>(a.bias + 16 * m + 4 * g);
 #pragma unroll
         for (int t = 0; t < WN; ++t) {
             acc[m][t] += bb;
@@ -378,17 +420,12 @@ __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
     for (int t = 0; t < WN; ++t) {
         part[t] += __shfl_xor(part[t], 16);
         part[t] += __shfl_xor(part[t], 32);
-        if (g == 0) ssq[wave][16 * t + n] = part[t];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < WN; ++t) {
-        const int pl = 16 * t + n, p = p0 + pl;
-        const float inv = 1.0f / sqrtf(ssq[0][pl] + ssq[1][pl] + ssq[2][pl] + ssq[3][pl] + 1e-10f);
+        const int p = p0 + 16 * t + n;
+        const float inv = 1.0f / sqrtf(part[t] + 1e-10f);
         if (p < a.n_patches) {
 #pragma unroll
-            for (int m = 0; m < WM; ++m)
-                *reinterpret_cast<f4 *>(a.desc + (size_t)p * kDesc + 16 * (wave * WM + m) + 4 * g) = acc[m][t] * inv;
+            for (int m = 0; m < MT; ++m)
+                *reinterpret_cast<f4 *>(a.desc + (size_t)p * kDesc + 16 * m + 4 * g) = acc[m][t] * inv;
         }
     }
 }
@@ -401,7 +438,16 @@ using CfgL6 = ConvCfg<128, 128, 8, 1, 8, false>;
 
 constexpr size_t kBufA = (size_t)2 * 32 * 32 * 32 * 2;      // a2 (largest tenant): 128 KiB per patch
 constexpr size_t kBufB = (size_t)2 * 16 * 16 * 64 * 2;      // a3: 64 KiB per patch
-constexpr int kChunk = 4096;                                // patches per pass through the layer kernels
+constexpr size_t kBufA6 = (size_t)2 * kFcK * 2;             // a6: 32 KiB per patch, kept for the whole batch
+constexpr int kChunkDefault = 4096;                         // patches per pass through the convolution kernels
+int hn_chunk() {
+    static const int c = [] {
+        const char *e = getenv("BALF_HN_CHUNK");            // tuning aid
+        const int v = e ? atoi(e) : 0;
+        return v >= 64 ? v : kChunkDefault;
+    }();
+    return c;
+}
 
 template <typename Cfg>
 int launch_conv(int slot, const ConvArgs &a, hipStream_t st) {
@@ -478,8 +524,8 @@ extern "C" int balf_hardnet_pack_weights(const float *const *tensors, int n_tens
 
 extern "C" size_t balf_hardnet_workspace_bytes(int n_patches) {
     if (n_patches <= 0) return 0;
-    const size_t c = n_patches < kChunk ? n_patches : kChunk;
-    return c * (kBufA + kBufB);
+    const size_t c = n_patches < hn_chunk() ? n_patches : hn_chunk();
+    return c * (kBufA + kBufB) + (size_t)n_patches * kBufA6;
 }
 
 extern "C" int balf_hardnet_forward(const void *packed_dev, const float *patches_dev, int n_patches, float *desc_dev,
@@ -488,9 +534,10 @@ extern "C" int balf_hardnet_forward(const void *packed_dev, const float *patches
     if (workspace_bytes < balf_hardnet_workspace_bytes(n_patches)) return BALF_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const char *blob = static_cast<const char *>(packed_dev);
-    const int chunk = n_patches < kChunk ? n_patches : kChunk;
+    const int chunk = n_patches < hn_chunk() ? n_patches : hn_chunk();
     char *bufA = static_cast<char *>(workspace_dev);
     char *bufB = bufA + (size_t)chunk * kBufA;
+    char *a6 = bufB + (size_t)chunk * kBufB;
     auto bias = [&](int l) { return reinterpret_cast<const float *>(blob + hn_boff(l)); };
     for (int c0 = 0; c0 < n_patches; c0 += chunk) {
         const int n = n_patches - c0 < chunk ? n_patches - c0 : chunk;
@@ -506,11 +553,12 @@ extern "C" int balf_hardnet_forward(const void *packed_dev, const float *patches
         if ((rc = launch_conv<CfgL4>(balf_prof::kHnConv4, a, st)) != BALF_OK) return rc;
         a.in = bufA; a.out = bufB; a.w = blob + hn_woff(4); a.bias = bias(4);
         if ((rc = launch_conv<CfgL5>(balf_prof::kHnConv5, a, st)) != BALF_OK) return rc;
-        a.in = bufB; a.out = bufA; a.w = blob + hn_woff(5); a.bias = bias(5);
+        a.in = bufB; a.out = a6 + (size_t)c0 * kBufA6; a.w = blob + hn_woff(5); a.bias = bias(5);
         if ((rc = launch_conv<CfgL6>(balf_prof::kHnConv6, a, st)) != BALF_OK) return rc;
-        FcArgs f{reinterpret_cast<const _Float16 *>(bufA), desc_dev + (size_t)c0 * kDesc, blob + hn_woff(6), bias(6), n};
-        BALF_PROF(balf_prof::kHnFc, st, (hn_fc_kernel<<<balf_ceil_div(n, 64), 256, 0, st>>>(f)));
-        BALF_LAUNCH_CHECK();
     }
+    // the final GEMM runs once over the whole batch (a chunk alone would fill 32 of the 256 CUs)
+    FcArgs f{reinterpret_cast<const _Float16 *>(a6), desc_dev, blob + hn_woff(6), bias(6), n_patches};
+    BALF_PROF(balf_prof::kHnFc, st, (hn_fc_kernel<<<balf_ceil_div(n_patches, 128), 256, kFcLds, st>>>(f)));
+    BALF_LAUNCH_CHECK();
     return BALF_OK;
 }

@@ -1,0 +1,272 @@
+// Repeatability evaluation on gfx950.
+//
+// Reference: /root/reference/balf/benchmark_test/repeatability_tools.py:379-512 (compute_repeatability,
+// intersection_area, union_area) and /root/reference/balf/benchmark_test/geometry_tools.py:43-86
+// (apply_homography_to_points, getAff).  The reference walks all Ns x Nd pairs in a Python double loop, fills two
+// dense overlap matrices, argsorts each and assigns greedily; callers: train_utils.py:189,257 (validation) and
+// datasets/dataset_utils.py:332.
+//
+// Here nothing dense is stored.  All arithmetic is float64, like the reference's Python floats:
+//   rep_count_kernel   one workgroup per source point: circle-overlap of every pair, counts the pairs whose
+//                      single-scale / multi-scale overlap reaches 1 - overlap_err, and the "possible match" flag
+//   rep_scan_kernel    exclusive scan of the per-row counts
+//   rep_fill_kernel    one wave per source point: ordered compaction of the candidate pairs (key = overlap bits,
+//                      value = flat index i*Nd + j, written in flat order)
+//   hipcub radix sort  stable, descending by overlap => equal overlaps stay in flat-index order
+//   rep_greedy_kernel  one wave walks the sorted candidates 64 at a time; visited bitmaps in LDS; the error sum is
+//                      accumulated in the reference's order
+// The candidate count is data dependent, so balf_repeatability synchronises the stream once to read it.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace balf {
+namespace {
+
+constexpr double kPi = 3.141592653589793;
+constexpr double kEpsF64 = 2.220446049250313e-16;          // np.finfo(float).eps
+constexpr double kEpsF32 = 1.1920928955078125e-07;         // np.finfo(np.float32).eps
+constexpr int kMaxPoints = 65536;                          // visited bitmaps live in LDS
+
+struct RepParams {
+    double thr, eps, dist_match, radius, max_dist;
+};
+
+__device__ __forceinline__ double inter_area(double R, double r, double d) {
+    if (d <= fabs(R - r)) { const double m = fmin(R, r); return kPi * (m * m); }
+    if (d >= r + R) return 0.0;
+    const double r2 = r * r, R2 = R * R, d2 = d * d;
+    const double alpha = acos((d2 + r2 - R2) / (2 * d * r));
+    const double beta = acos((d2 + R2 - r2) / (2 * d * R));
+    return r2 * alpha + R2 * beta - 0.5 * (r2 * sin(2 * alpha) + R2 * sin(2 * beta));
+}
+
+__device__ __forceinline__ void pair_overlaps(double sx, double sy, double sr, double tx, double ty, double tr,
+                                              const RepParams &p, double &single, double &multi, bool &possible) {
+    const double dx = sx - tx, dy = sy - ty;
+    const double dist = sqrt(dx * dx + dy * dy);
+    possible = dist <= p.dist_match;
+    single = 0.0; multi = 0.0;
+    if (dist > p.max_dist) return;
+    const double f = p.radius / (fmax(sr, tr) + kEpsF64);
+    double I = inter_area(f * sr, f * tr, dist);
+    double U = kPi * ((f * sr) * (f * sr)) + kPi * ((f * tr) * (f * tr)) - I + p.eps;
+    multi = I / U;
+    I = inter_area(p.radius, p.radius, dist);
+    U = kPi * (p.radius * p.radius) + kPi * (p.radius * p.radius) - I + p.eps;
+    single = I / U;
+}
+
+__global__ __launch_bounds__(256) void rep_count_kernel(const double *src, int ns, const double *dst, int nd, RepParams p,
+                                                        int *cnt_s, int *cnt_m, int *poss) {
+    __shared__ int red[3];
+    const int i = blockIdx.x;
+    if (threadIdx.x < 3) red[threadIdx.x] = 0;
+    __syncthreads();
+    const double sx = src[3 * i], sy = src[3 * i + 1], sr = src[3 * i + 2];
+    int cs = 0, cm = 0, ps = 0;
+    for (int j = threadIdx.x; j < nd; j += 256) {
+        double s, m; bool po;
+        pair_overlaps(sx, sy, sr, dst[3 * j], dst[3 * j + 1], dst[3 * j + 2], p, s, m, po);
+        cs += s >= p.thr; cm += m >= p.thr; ps |= po;
+    }
+    if (cs) atomicAdd(&red[0], cs);
+    if (cm) atomicAdd(&red[1], cm);
+    if (ps) atomicOr(&red[2], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { cnt_s[i] = red[0]; cnt_m[i] = red[1]; poss[i] = red[2]; }
+}
+
+// off[i] = sum_{k<i} cnt[k]; totals = {sum cnt_s, sum cnt_m, sum poss}
+__global__ __launch_bounds__(1024) void rep_scan_kernel(const int *cnt_s, const int *cnt_m, const int *poss, int ns,
+                                                        int *off_s, int *off_m, int *totals) {
+    __shared__ int wsum[3][16];
+    __shared__ int base[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 3) base[tid] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < ns; i0 += 1024) {
+        const int i = i0 + tid;
+        int v[3] = {i < ns ? cnt_s[i] : 0, i < ns ? cnt_m[i] : 0, i < ns ? poss[i] : 0};
+        int incl[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int x = v[c];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(x, o);
+                if (lane >= o) x += y;
+            }
+            incl[c] = x;
+            if (lane == 63) wsum[c][wave] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int before = base[c];
+            for (int w = 0; w < wave; ++w) before += wsum[c][w];
+            incl[c] += before;
+        }
+        if (i < ns) { off_s[i] = incl[0] - v[0]; off_m[i] = incl[1] - v[1]; }
+        __syncthreads();
+        if (tid == 1023) { base[0] = incl[0]; base[1] = incl[1]; base[2] = incl[2]; }
+        __syncthreads();
+    }
+    if (tid == 0) { totals[0] = base[0]; totals[1] = base[1]; totals[2] = base[2]; }
+}
+
+__global__ __launch_bounds__(64) void rep_fill_kernel(const double *src, int ns, const double *dst, int nd, RepParams p,
+                                                      const int *off_s, const int *off_m, unsigned long long *key_s,
+                                                      unsigned *val_s, unsigned long long *key_m, unsigned *val_m) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const double sx = src[3 * i], sy = src[3 * i + 1], sr = src[3 * i + 2];
+    int ws = off_s[i], wm = off_m[i];
+    for (int j0 = 0; j0 < nd; j0 += 64) {
+        const int j = j0 + lane;
+        double s = 0.0, m = 0.0; bool po;
+        if (j < nd) pair_overlaps(sx, sy, sr, dst[3 * j], dst[3 * j + 1], dst[3 * j + 2], p, s, m, po);
+        const bool ks = j < nd && s >= p.thr, km = j < nd && m >= p.thr;
+        const unsigned long long bs = __ballot(ks), bm = __ballot(km);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (ks) { const int o = ws + __popcll(bs & below); key_s[o] = __double_as_longlong(s); val_s[o] = (unsigned)(i * nd + j); }
+        if (km) { const int o = wm + __popcll(bm & below); key_m[o] = __double_as_longlong(m); val_m[o] = (unsigned)(i * nd + j); }
+        ws += __popcll(bs); wm += __popcll(bm);
+    }
+}
+
+// out: found[which], err[which], corr[which][k] = (x_pos = dst index, y_pos = src index) in assignment order
+__global__ __launch_bounds__(64) void rep_greedy_kernel(const unsigned long long *keys, const unsigned *vals, int n_edges, int nd,
+                                                        int *found_out, double *err_out, int *corr, int cap) {
+    __shared__ unsigned vis_x[kMaxPoints / 32], vis_y[kMaxPoints / 32];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < kMaxPoints / 32; k += 64) { vis_x[k] = 0u; vis_y[k] = 0u; }
+    __syncthreads();
+    int found = 0;
+    double err = 0.0;
+    for (int base = 0; base < n_edges; base += 64) {
+        const int e = base + lane;
+        unsigned idx = 0; double w = 0.0;
+        if (e < n_edges) { idx = vals[e]; w = __longlong_as_double((long long)keys[e]); }
+        const int yi = (int)(idx / (unsigned)nd), xj = (int)(idx % (unsigned)nd);
+        const int lim = n_edges - base < 64 ? n_edges - base : 64;
+        for (int l = 0; l < lim; ++l) {
+            const int y = __shfl(yi, l), x = __shfl(xj, l);
+            const double wl = __shfl(w, l);
+            const bool taken = ((vis_x[x >> 5] >> (x & 31)) & 1u) || ((vis_y[y >> 5] >> (y & 31)) & 1u);
+            if (!taken) {
+                if (lane == 0) {
+                    vis_x[x >> 5] |= 1u << (x & 31);
+                    vis_y[y >> 5] |= 1u << (y & 31);
+                    if (found < cap) { corr[2 * found] = x; corr[2 * found + 1] = y; }
+                }
+                found += 1;
+                err += 1.0 - wl;
+            }
+            __syncthreads();        // single wave: orders lane 0's LDS update before the next read
+        }
+    }
+    if (lane == 0) { *found_out = found; *err_out = err; }
+    for (int k = found + lane; k < cap; k += 64) { corr[2 * k] = -1; corr[2 * k + 1] = -1; }
+}
+
+__global__ void homography_kernel(const double *pts, int n, const double *h, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = pts[4 * i], y = pts[4 * i + 1], r = pts[4 * i + 2];
+    const double den = h[6] * x + h[7] * y + h[8];
+    const double nx = h[0] * x + h[1] * y + h[2], ny = h[3] * x + h[4] * y + h[5];
+    const double fxdx = h[0] / den - nx * h[6] / (den * den), fxdy = h[1] / den - nx * h[7] / (den * den);
+    const double fydx = h[3] / den - ny * h[6] / (den * den), fydy = h[4] / den - ny * h[7] / (den * den);
+    const double tmp = r * r + kEpsF32;
+    out[4 * i] = nx / den; out[4 * i + 1] = ny / den;
+    out[4 * i + 2] = sqrt(tmp * fabs(fxdx * fydy - fxdy * fydx));
+    out[4 * i + 3] = pts[4 * i + 3];
+}
+
+size_t sort_temp_bytes(int max_edges) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, (const unsigned long long *)nullptr,
+                                                       (unsigned long long *)nullptr, (const unsigned *)nullptr,
+                                                       (unsigned *)nullptr, max_edges);
+    return bytes;
+}
+
+struct RepWs {
+    int *cnt_s, *cnt_m, *poss, *off_s, *off_m, *totals;
+    unsigned long long *key_s, *key_m, *key_out;      // candidate lists (both filled in one pass), sorted keys
+    unsigned *val_s, *val_m, *val_out;
+    void *temp;
+    size_t temp_bytes, total;
+};
+
+RepWs rep_layout(char *base, int ns, int max_edges) {
+    RepWs w{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char *p = base ? base + o : nullptr; o += balf_align_up(bytes, 256); return p; };
+    w.cnt_s = (int *)take((size_t)ns * 4); w.cnt_m = (int *)take((size_t)ns * 4); w.poss = (int *)take((size_t)ns * 4);
+    w.off_s = (int *)take((size_t)ns * 4); w.off_m = (int *)take((size_t)ns * 4); w.totals = (int *)take(16);
+    w.key_s = (unsigned long long *)take((size_t)max_edges * 8); w.key_m = (unsigned long long *)take((size_t)max_edges * 8);
+    w.key_out = (unsigned long long *)take((size_t)max_edges * 8);
+    w.val_s = (unsigned *)take((size_t)max_edges * 4); w.val_m = (unsigned *)take((size_t)max_edges * 4);
+    w.val_out = (unsigned *)take((size_t)max_edges * 4);
+    w.temp_bytes = sort_temp_bytes(max_edges);
+    w.temp = take(w.temp_bytes);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+}  // namespace balf
+
+using namespace balf;
+
+extern "C" size_t balf_repeatability_workspace_bytes(int ns, int nd, int max_edges) {
+    if (ns <= 0 || nd <= 0 || max_edges <= 0) return 0;
+    return rep_layout(nullptr, ns, max_edges).total;
+}
+
+extern "C" int balf_repeatability(const double *src_dev, int ns, const double *dst_dev, int nd, double overlap_err,
+                                  double eps, double dist_match_thresh, double radius_size, int max_edges,
+                                  int32_t *counts_dev, double *errors_dev, int32_t *corr_s_dev, int32_t *corr_m_dev,
+                                  void *workspace_dev, size_t workspace_bytes, void *stream) {
+    if (!src_dev || !dst_dev || !counts_dev || !errors_dev || !corr_s_dev || !corr_m_dev || !workspace_dev) return BALF_ERR_ARG;
+    if (ns <= 0 || nd <= 0 || max_edges <= 0 || ns > kMaxPoints || nd > kMaxPoints) return BALF_ERR_ARG;
+    if ((long long)ns * nd > 0x7fffffffLL) return BALF_ERR_SHAPE;
+    if (workspace_bytes < balf_repeatability_workspace_bytes(ns, nd, max_edges)) return BALF_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RepWs w = rep_layout(static_cast<char *>(workspace_dev), ns, max_edges);
+    const RepParams p{1.0 - overlap_err, eps, dist_match_thresh, radius_size, 4.0 * radius_size};
+    rep_count_kernel<<<ns, 256, 0, st>>>(src_dev, ns, dst_dev, nd, p, w.cnt_s, w.cnt_m, w.poss);
+    BALF_LAUNCH_CHECK();
+    rep_scan_kernel<<<1, 1024, 0, st>>>(w.cnt_s, w.cnt_m, w.poss, ns, w.off_s, w.off_m, w.totals);
+    BALF_LAUNCH_CHECK();
+    int totals[3] = {0, 0, 0};
+    if (hipMemcpyAsync(totals, w.totals, sizeof(totals), hipMemcpyDeviceToHost, st) != hipSuccess) return BALF_ERR_LAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return BALF_ERR_LAUNCH;
+    if (totals[0] > max_edges || totals[1] > max_edges) return BALF_ERR_WORKSPACE;
+    rep_fill_kernel<<<ns, 64, 0, st>>>(src_dev, ns, dst_dev, nd, p, w.off_s, w.off_m, w.key_s, w.val_s, w.key_m, w.val_m);
+    BALF_LAUNCH_CHECK();
+    const int cap = ns < nd ? ns : nd;
+    for (int which = 0; which < 2; ++which) {
+        const int ne = totals[which];
+        const unsigned long long *kin = which ? w.key_m : w.key_s;
+        const unsigned *vin = which ? w.val_m : w.val_s;
+        if (ne > 0) {
+            size_t tb = w.temp_bytes;
+            if (hipcub::DeviceRadixSort::SortPairsDescending(w.temp, tb, kin, w.key_out, vin, w.val_out, ne, 0, 64, st) != hipSuccess)
+                return BALF_ERR_LAUNCH;
+        }
+        rep_greedy_kernel<<<1, 64, 0, st>>>(w.key_out, w.val_out, ne, nd, counts_dev + which, errors_dev + which,
+                                            which ? corr_m_dev : corr_s_dev, cap);
+        BALF_LAUNCH_CHECK();
+    }
+    if (hipMemcpyAsync(counts_dev + 2, w.totals + 2, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return BALF_ERR_LAUNCH;
+    return BALF_OK;
+}
+
+extern "C" int balf_apply_homography(const double *points_dev, int n, const double *h_dev, double *out_dev, void *stream) {
+    if (!points_dev || !h_dev || !out_dev || n <= 0) return BALF_ERR_ARG;
+    homography_kernel<<<balf_ceil_div(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(points_dev, n, h_dev, out_dev);
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}

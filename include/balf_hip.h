@@ -153,6 +153,25 @@ size_t balf_match_smnn_workspace_bytes(int n1, int n2);
 int balf_match_smnn(const float *desc1_dev, int n1, const float *desc2_dev, int n2, float th, int32_t *idx_dev,
                     float *dist_dev, int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* ---- repeatability evaluation ---------------------------------------------------------
+ * balf_repeatability replaces compute_repeatability, balf/benchmark_test/repeatability_tools.py:379-490 (callers:
+ * balf/utils/train_utils.py:189,257, balf/datasets/dataset_utils.py:332).  src_dev [ns,3] / dst_dev [nd,3] float64
+ * rows (x, y, radius).  Outputs: counts_dev[3] = {num_points_single_scale, num_points_multi_scale,
+ * possible_matches}; errors_dev[2] = the two sums of (1 - overlap) over the assigned pairs, in assignment order;
+ * corr_s_dev / corr_m_dev [min(ns,nd),2] = (dst index, src index) per assigned pair in assignment order, -1 padded.
+ * Among exactly equal overlaps the pair with the lower flat index ns-major wins (the reference's order there is
+ * NumPy's unstable argsort).  max_edges bounds the number of pairs whose overlap reaches 1 - overlap_err
+ * (BALF_ERR_WORKSPACE when exceeded).  The candidate count is data dependent: this entry point calls
+ * hipStreamSynchronize(stream) once.  ns, nd <= 65536.
+ * balf_apply_homography replaces apply_homography_to_points, balf/benchmark_test/geometry_tools.py:43-86:
+ * points_dev [n,4] float64 rows (x, y, radius, score), h_dev[9] row-major -> out_dev [n,4]. */
+size_t balf_repeatability_workspace_bytes(int ns, int nd, int max_edges);
+int balf_repeatability(const double *src_dev, int ns, const double *dst_dev, int nd, double overlap_err, double eps,
+                       double dist_match_thresh, double radius_size, int max_edges, int32_t *counts_dev,
+                       double *errors_dev, int32_t *corr_s_dev, int32_t *corr_m_dev, void *workspace_dev,
+                       size_t workspace_bytes, void *stream);
+int balf_apply_homography(const double *points_dev, int n, const double *h_dev, double *out_dev, void *stream);
+
 /* ---- measurement aid (not part of the data path) ---------------------------------------------
  * Between balf_profile_begin() and balf_profile_end() every kernel launch of the library is bracketed
  * by a hipEvent pair on its launch stream.  balf_profile_end() waits for those events and returns,

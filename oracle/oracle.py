@@ -365,3 +365,94 @@ def match_smnn(d1: torch.Tensor, d2: torch.Tensor, th: float = 0.99):
     if not out_i:
         return torch.zeros(0, dtype=d1.dtype), torch.zeros(0, 2, dtype=torch.int64)
     return torch.tensor(out_r, dtype=d1.dtype), torch.tensor(out_i, dtype=torch.int64)
+
+
+# ----------------------------------------------------------------------------------------
+# repeatability evaluation
+# ----------------------------------------------------------------------------------------
+def _circle_intersection(R, r, d):
+    """/root/reference/balf/benchmark_test/repeatability_tools.py:492-508, vectorised (float64)."""
+    R, r, d = np.broadcast_arrays(np.asarray(R, np.float64), np.asarray(r, np.float64), np.asarray(d, np.float64))
+    out = np.zeros(d.shape, np.float64)
+    inside = d <= np.abs(R - r)
+    out[inside] = np.pi * np.minimum(R, r)[inside] ** 2
+    mid = ~inside & ~(d >= r + R)
+    r2, R2, d2 = r[mid] ** 2, R[mid] ** 2, d[mid] ** 2
+    alpha = np.arccos((d2 + r2 - R2) / (2 * d[mid] * r[mid]))
+    beta = np.arccos((d2 + R2 - r2) / (2 * d[mid] * R[mid]))
+    out[mid] = r2 * alpha + R2 * beta - 0.5 * (r2 * np.sin(2 * alpha) + R2 * np.sin(2 * beta))
+    return out
+
+
+def _greedy_assign(overlaps: np.ndarray, thr: float):
+    """Greedy one-to-one assignment in descending overlap (repeatability_tools.py:424-441): ties broken by flat
+    index (the reference's order among exactly equal overlaps is NumPy's unstable argsort)."""
+    n_dst = overlaps.shape[1]
+    flat = overlaps.ravel()
+    cand = np.flatnonzero(flat >= thr)
+    order = cand[np.lexsort((cand, -flat[cand]))]
+    y_vis = np.zeros(overlaps.shape[0], bool)
+    x_vis = np.zeros(n_dst, bool)
+    found, err, corr = 0, 0.0, []
+    for idx in order:
+        y, x = idx // n_dst, idx % n_dst
+        if x_vis[x] or y_vis[y]:
+            continue
+        found += 1
+        err += 1 - flat[idx]
+        corr.append([x, y])
+        x_vis[x] = y_vis[y] = True
+    return found, err, np.asarray(corr)
+
+
+def compute_repeatability(src, dst, overlap_err=0.4, eps=1e-6, dist_match_thresh=3, radious_size=30.0):
+    """/root/reference/balf/benchmark_test/repeatability_tools.py:379-490 restated with NumPy: src/dst rows
+    (x, y, radius, ...).  Pinned by tests/golden/repeatability.npz (recorded by executing the reference's own
+    function bodies, extracted with ``ast`` because the module imports torchvision)."""
+    src, dst = np.asarray(src, np.float64), np.asarray(dst, np.float64)
+    ns, nd = len(src), len(dst)
+    dx = src[:, None, 0] - dst[None, :, 0]
+    dy = src[:, None, 1] - dst[None, :, 1]
+    dist = (dx ** 2 + dy ** 2) ** 0.5
+    possible = int((dist <= dist_match_thresh).any(axis=1).sum()) if nd else 0
+    near = dist <= 4 * radious_size
+    rr, rd = np.broadcast_arrays(src[:, None, 2], dst[None, :, 2])
+    factor = radious_size / (np.maximum(rr, rd) + np.finfo(float).eps)
+    inter = _circle_intersection(factor * rr, factor * rd, dist)
+    union = np.pi * (factor * rr) ** 2 + np.pi * (factor * rd) ** 2 - inter + eps
+    multi = np.where(near, inter / union, 0.0)
+    inter = _circle_intersection(radious_size, radious_size, dist)
+    union = np.pi * radious_size ** 2 + np.pi * radious_size ** 2 - inter + eps
+    single = np.where(near, inter / union, 0.0)
+    thr = 1 - overlap_err
+    fs, es, cs = _greedy_assign(single, thr)
+    fm, em, cm = _greedy_assign(multi, thr)
+    points = min(ns, nd)
+    return {"rep_single_scale": fs / np.asarray(points, float) * 100.0,
+            "rep_multi_scale": fm / np.asarray(points, float) * 100.0,
+            "num_points_single_scale": fs, "num_points_multi_scale": fm,
+            "error_overlap_single_scale": 0.0 if fs == 0 else es / float(fs + np.finfo(float).eps),
+            "error_overlap_multi_scale": 0.0 if fm == 0 else em / float(fm + np.finfo(float).eps),
+            "total_num_points": points, "correspondences": cs, "possible_matches": possible,
+            "correspondences_m": cm}
+
+
+def apply_homography_to_points(points, h):
+    """/root/reference/balf/benchmark_test/geometry_tools.py:43-86 restated in closed form: (x, y) through the
+    homography; the radius is scaled by the local affine approximation A of the warp.  The reference builds
+    B = inv(A (r^2 + eps32) I A^T) and returns 1 / sqrt(sqrt(eig1 eig2)) = sqrt((r^2 + eps32) |det A|)."""
+    pts = np.asarray(points, np.float64)
+    if len(pts) == 0:
+        return np.zeros((0, 4))
+    h = np.asarray(h, np.float64)
+    x, y = pts[:, 0], pts[:, 1]
+    den = h[2, 0] * x + h[2, 1] * y + h[2, 2]
+    nx = h[0, 0] * x + h[0, 1] * y + h[0, 2]
+    ny = h[1, 0] * x + h[1, 1] * y + h[1, 2]
+    fxdx = h[0, 0] / den - nx * h[2, 0] / den ** 2
+    fxdy = h[0, 1] / den - nx * h[2, 1] / den ** 2
+    fydx = h[1, 0] / den - ny * h[2, 0] / den ** 2
+    fydy = h[1, 1] / den - ny * h[2, 1] / den ** 2
+    tmp = pts[:, 2] ** 2 + np.finfo(np.float32).eps
+    rad = np.sqrt(tmp * np.abs(fxdx * fydy - fxdy * fydx))
+    return np.stack([nx / den, ny / den, rad, pts[:, 3]], axis=1)

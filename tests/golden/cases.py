@@ -99,3 +99,32 @@ GREEDY_CASES = {
 HARDNET_SEED = 515
 HARDNET_CASES = {"n5": (5, 1), "n70": (70, 2)}
 HARDNET_TAP_CASE = "n5"          # per-layer activations of patch 0, every 4th channel
+
+
+# repeatability evaluation: name -> dict(ns, nd, seed, planted correspondences, kwargs of compute_repeatability)
+REPEAT_CASES = {
+    "small":      dict(ns=40, nd=55, seed=1, planted=25, kw={}),
+    "train_eval": dict(ns=150, nd=130, seed=2, planted=90, kw={}),                                  # train_utils.py:189 defaults
+    "hpatches":   dict(ns=300, nd=300, seed=3, planted=200, kw=dict(overlap_err=1 - 0.6, dist_match_thresh=5)),   # dataset_utils.py:332
+    "no_match":   dict(ns=20, nd=20, seed=4, planted=0, kw={}),
+    "crowded":    dict(ns=120, nd=120, seed=5, planted=120, kw=dict(overlap_err=0.7), spread=60.0),
+}
+
+
+def repeat_inputs(spec):
+    """src rows (x, y, radius, score); dst = warped + jittered copies of some src points plus outliers."""
+    rng = np.random.default_rng(9000 + spec["seed"])
+    spread = spec.get("spread", 600.0)
+    src = np.stack([rng.uniform(20, 20 + spread, spec["ns"]), rng.uniform(20, 20 + 0.75 * spread, spec["ns"]),
+                    rng.uniform(0.6, 3.0, spec["ns"]), rng.uniform(0, 1, spec["ns"])], axis=1)
+    dst = np.stack([rng.uniform(20, 20 + spread, spec["nd"]), rng.uniform(20, 20 + 0.75 * spread, spec["nd"]),
+                    rng.uniform(0.6, 3.0, spec["nd"]), rng.uniform(0, 1, spec["nd"])], axis=1)
+    k = min(spec["planted"], spec["ns"], spec["nd"])
+    if k:
+        pick_s, pick_d = rng.permutation(spec["ns"])[:k], rng.permutation(spec["nd"])[:k]
+        dst[pick_d, :2] = src[pick_s, :2] + rng.normal(0, 4.0, (k, 2))
+        dst[pick_d, 2] = src[pick_s, 2] * rng.uniform(0.7, 1.4, k)
+    return src, dst
+
+
+HOMOGRAPHY = np.array([[1.05, 0.08, -12.0], [-0.06, 0.97, 9.0], [1.2e-4, -0.8e-4, 1.0]])

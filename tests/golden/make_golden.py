@@ -13,6 +13,9 @@ What is recorded is data only -- inputs are regenerated from seeds, outputs are 
   nms_topk.npz        remove_borders/apply_nms/find_index_higher_scores results on synthetic
                       score maps (random, tie-heavy, all-zero, sparse, even window sizes)
   geometry.json       pad/crop shapes+offsets, state-dict table, checkpoint-loader behaviour
+  repeatability.npz   compute_repeatability / apply_homography_to_points results; those two modules import
+                      torchvision / cv2 / torchgeometry (absent offline), so the reference's own function bodies are
+                      extracted with ast from the files under /root/reference and executed as they are
   hardnet.npz         descriptors (+ per-layer activations of one patch) of the reference's HardNet class with the
                       seeded synthetic weights, on synthetic patches
 """
@@ -39,6 +42,19 @@ from balf_amd.utils import synth                            # noqa: E402
 from tests.golden import cases                              # noqa: E402
 
 torch.set_num_threads(8)
+
+
+def ref_functions(path, names, extra=None):
+    """Compile the named top-level functions of a reference source file, unchanged, into a fresh namespace (the
+    module itself cannot be imported here: it pulls in packages that are not installed)."""
+    import ast
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in keep) == sorted(names)
+    ns = {"np": np}
+    ns.update(extra or {})
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
 
 
 def ref_model(seed):
@@ -153,6 +169,20 @@ def main():
             hk[f"{name}.act{j}"] = a[0, ::4].copy()
     hk["state_keys"] = np.array(list(hn.state_dict().keys()))
     np.savez_compressed(os.path.join(HERE, "hardnet.npz"), **hk)
+
+    # ---------------- repeatability evaluation ----------------
+    rt = ref_functions("/root/reference/balf/benchmark_test/repeatability_tools.py",
+                       ["compute_repeatability", "intersection_area", "union_area"])
+    gt = ref_functions("/root/reference/balf/benchmark_test/geometry_tools.py", ["apply_homography_to_points", "getAff"])
+    rp = {}
+    for name, spec in cases.REPEAT_CASES.items():
+        src, dst = cases.repeat_inputs(spec)
+        res = rt["compute_repeatability"](src, dst, **spec["kw"])
+        for k_, v_ in res.items():
+            rp[f"{name}.{k_}"] = np.asarray(v_)
+    src, _ = cases.repeat_inputs(cases.REPEAT_CASES["small"])
+    rp["homography.points"] = gt["apply_homography_to_points"](src, cases.HOMOGRAPHY)
+    np.savez_compressed(os.path.join(HERE, "repeatability.npz"), **rp)
 
     # ---------------- geometry, state-dict table, loader behaviour ----------------
     geo = {"pad": {}, "state": [], "loader": {}}

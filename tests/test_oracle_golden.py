@@ -160,3 +160,24 @@ def test_extract_patches_oracle_identity_scale():
     mid = 0.25 * (p[0, 0, 15, 15] + p[0, 0, 15, 16] + p[0, 0, 16, 15] + p[0, 0, 16, 16])
     gx, gy = 64.0 * w / (w - 1) - 0.5, 48.0 * h / (h - 1) - 0.5           # where kornia's mixed conventions land
     assert abs(float(mid) - (gy * w + gx) / (h * w)) < 1e-4
+
+
+# ---------------- repeatability evaluation ----------------
+@pytest.mark.parametrize("name", list(cases.REPEAT_CASES))
+def test_repeatability_oracle_matches_reference_goldens(name):
+    g = np.load(os.path.join(G, "repeatability.npz"))
+    spec = cases.REPEAT_CASES[name]
+    src, dst = cases.repeat_inputs(spec)
+    r = O.compute_repeatability(src, dst, **spec["kw"])
+    for k, v in r.items():
+        ref, v = g[f"{name}.{k}"], np.asarray(v)
+        if v.dtype.kind in "iu" or ref.dtype.kind in "iu":
+            assert np.array_equal(v.reshape(-1), ref.reshape(-1)), k
+        else:
+            assert np.allclose(v, ref, rtol=0, atol=1e-12), k
+
+
+def test_homography_oracle_matches_reference_golden():
+    g = np.load(os.path.join(G, "repeatability.npz"))
+    src, _ = cases.repeat_inputs(cases.REPEAT_CASES["small"])
+    assert np.abs(O.apply_homography_to_points(src, cases.HOMOGRAPHY) - g["homography.points"]).max() < 1e-11

@@ -1,0 +1,65 @@
+"""Repeatability evaluation: balf_repeatability / balf_apply_homography through the host mirror
+against the goldens recorded from the reference's own function bodies, and against the oracle on larger inputs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from balf_amd.benchmark_test import geometry_tools, repeatability_tools       # noqa: E402
+from oracle import oracle                                                      # noqa: E402
+from tests.golden import cases                                                 # noqa: E402
+
+pytestmark = pytest.mark.gpu
+INT_KEYS = ("num_points_single_scale", "num_points_multi_scale", "total_num_points", "possible_matches",
+            "correspondences", "correspondences_m")
+FLOAT_KEYS = ("rep_single_scale", "rep_multi_scale", "error_overlap_single_scale", "error_overlap_multi_scale")
+
+
+def _same(res, ref):
+    for k in INT_KEYS:
+        assert np.array_equal(np.asarray(res[k]).reshape(-1), np.asarray(ref[k]).reshape(-1)), k
+    for k in FLOAT_KEYS:
+        assert abs(float(res[k]) - float(ref[k])) < 1e-12, k
+
+
+@pytest.mark.parametrize("name", list(cases.REPEAT_CASES))
+def test_matches_reference_goldens(name):
+    g = np.load(os.path.join(HERE, "golden", "repeatability.npz"))
+    spec = cases.REPEAT_CASES[name]
+    src, dst = cases.repeat_inputs(spec)
+    res = repeatability_tools.compute_repeatability(src, dst, **spec["kw"])
+    _same(res, {k: g[f"{name}.{k}"] for k in INT_KEYS + FLOAT_KEYS})
+
+
+@pytest.mark.parametrize("ns,nd,planted", [(1000, 1000, 700), (2000, 1500, 1200), (1, 1, 1), (3, 700, 2)])
+def test_vs_oracle_at_benchmark_sizes(ns, nd, planted):
+    """1000 x 1000 is what the reference's HPatches evaluation feeds in (a 10^6-iteration Python loop there)."""
+    spec = dict(ns=ns, nd=nd, seed=77, planted=planted, kw={})
+    src, dst = cases.repeat_inputs(spec)
+    _same(repeatability_tools.compute_repeatability(src, dst), oracle.compute_repeatability(src, dst))
+
+
+def test_exact_ties_resolve_by_flat_index():
+    """Integer grids give many exactly equal distances; the kernel's documented tie-break (lower flat index first) is
+    the oracle's."""
+    ys, xs = np.mgrid[0:12, 0:12]
+    src = np.stack([xs.ravel() * 20.0, ys.ravel() * 20.0, np.ones(144), np.ones(144)], axis=1)
+    dst = src.copy()
+    dst[:, 0] += 6.0
+    _same(repeatability_tools.compute_repeatability(src, dst), oracle.compute_repeatability(src, dst))
+
+
+def test_empty_inputs():
+    r = repeatability_tools.compute_repeatability(np.zeros((0, 4)), np.zeros((5, 4)))
+    assert r["num_points_single_scale"] == 0 and r["total_num_points"] == 0 and r["possible_matches"] == 0
+
+
+def test_apply_homography_matches_reference_golden():
+    g = np.load(os.path.join(HERE, "golden", "repeatability.npz"))
+    src, _ = cases.repeat_inputs(cases.REPEAT_CASES["small"])
+    out = geometry_tools.apply_homography_to_points(src, cases.HOMOGRAPHY)
+    assert np.abs(out - g["homography.points"]).max() < 1e-11
