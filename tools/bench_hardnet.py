@@ -48,9 +48,33 @@ def main():
         if cnt[i] and l.balf_profile_slot_name(i).decode().startswith("hardnet"):
             print(f"  {l.balf_profile_slot_name(i).decode():18s} {ms[i]:8.3f} ms  ({cnt[i]} launches)")
     from oracle import oracle
-    sd64 = {k: v.double() for k, v in synth.synthetic_hardnet_state_dict(515).items()}
+    sd = synth.synthetic_hardnet_state_dict(515)
+    sd64 = {k: v.double() for k, v in sd.items()}
     ref = oracle.hardnet_forward(sd64, base[:256].cpu().double()).numpy()
-    print("max-abs descriptor error vs fp64 oracle:", float(np.abs(d[:256].cpu().numpy() - ref).max()))
+    err = float(np.abs(d[:256].cpu().numpy() - ref).max())
+    print("max-abs descriptor error vs fp64 oracle:", err)
+    # the reference's CPU path beside it (oracle port: same torch CPU ops as third_party/hardnet/hardnet_pytorch.py)
+    import json
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    xc = base[:1000].cpu()                       # one demo_match chunk (demo_match.py:73-76)
+    oracle.hardnet_forward(sd, xc[:64])
+    t0 = time.perf_counter()
+    oracle.hardnet_forward(sd, xc)
+    cpu_dt = time.perf_counter() - t0
+    dom = max((i for i in range(ns) if cnt[i] and l.balf_profile_slot_name(i).decode().startswith("hardnet")), key=lambda i: ms[i])
+    mac = {"hardnet_conv1_2": 9 * 32 * 1024 + 9 * 32 * 32 * 1024, "hardnet_conv3": 9 * 32 * 64 * 256,
+           "hardnet_conv4": 9 * 64 * 64 * 256, "hardnet_conv5": 9 * 64 * 128 * 64, "hardnet_conv6": 9 * 128 * 128 * 64,
+           "hardnet_fc": 64 * 128 * 128}[l.balf_profile_slot_name(dom).decode()]
+    ach = 2 * mac * n / (ms[dom] * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "HardNet descriptors/s (demo path, 32x32 patches -> 128-d)", "value": n / dt, "unit": "patches/s",
+        "n_patches": n, "ms": dt * 1e3, "dtype": "f16 MFMA, split hi+lo operands (3 products), f32 accumulate",
+        "max_abs_err_vs_fp64": err,
+        "roofline": {"kernel": l.balf_profile_slot_name(dom).decode(), "bound": "mfma", "achieved": ach,
+                     "peak": 2500.0 / 3, "unit": "TFLOP/s", "frac": ach / (2500.0 / 3),
+                     "note": "algorithmic FLOP (one product per MAC) against the f16 dense peak / 3 split products"},
+        "cpu_baseline": {"value": 1000 / cpu_dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+                         "sample": f"1000 patches, oracle.hardnet_forward (torch CPU fp32), {cpu_dt:.2f} s"}}))
 
 
 if __name__ == "__main__":
