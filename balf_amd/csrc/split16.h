@@ -29,6 +29,9 @@ __device__ __forceinline__ f4x mfma16x3(const HL &a, const HL &b, f4x c) {
 #ifndef BALF_ABLATE_SPLIT
 #define BALF_ABLATE_SPLIT 0
 #endif
+#ifndef BALF_SPLIT_MIX
+#define BALF_SPLIT_MIX 1
+#endif
 __device__ __forceinline__ void split_pair(float v0, float v1, h2 &hi, h2 &lo) {
     if (BALF_ABLATE_SPLIT) {                       // timing experiment: one convert, no residual
         typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
@@ -39,8 +42,19 @@ __device__ __forceinline__ void split_pair(float v0, float v1, h2 &hi, h2 &lo) {
     typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
     const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);      // hi = rtz_f16(v); v - hi is exact in fp32
     hi = __builtin_bit_cast(h2, h);
+#if BALF_SPLIT_MIX
+    // lo = f16(v - hi) straight from the packed halves: v_fma_mix{lo,hi}_f16 read hi as f16, v as f32, and write
+    // one half of the destination each -- 3 instructions per pair instead of the 5 hipcc emits for the casts
+    const unsigned hu = __builtin_bit_cast(unsigned, h);
+    unsigned lu;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lu) : "v"(hu), "v"(v0), "v"(v1));
+    lo = __builtin_bit_cast(h2, lu);
+#else
     const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(fmaf((float)hi[0], -1.0f, v0), fmaf((float)hi[1], -1.0f, v1));
     lo = __builtin_bit_cast(h2, l);
+#endif
 }
 
 
