@@ -1,0 +1,78 @@
+"""The BASELINE.json configurations end to end (uint8 images in, keypoints out) at their full batch sizes:
+cfg1 32 x VGA top-1000, cfg2 64 x 720p top-2000 fp32, cfg3/cfg4 1080p shards (32 per GPU; 128 on one GPU, f16 path).
+Checked per configuration: (i) NMS/top-K of every image is bit-exact against the C oracle run on the very score
+map the GPU produced ("NMS indices bit-exact on identical input"), (ii) the batch is invisible (an image alone gives
+the same bits), (iii) every image yields its K keypoints, (iv) score map of one image against the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from balf_amd import arch, pipeline                                   # noqa: E402
+from balf_amd.model import get_model                                  # noqa: E402
+from balf_amd.utils import synth                                      # noqa: E402
+from oracle import c_oracle, oracle                                   # noqa: E402
+from tests.golden import cases                                        # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(precision):
+    m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m.load_state_dict(synth.synthetic_state_dict(cases.WEIGHT_SEED))
+    m.precision = precision
+    return m.eval().to(DEV)
+
+
+def _images(b, h, w):
+    base = [synth.synthetic_gray_u8(h, w, i) for i in range(4)]          # 4 distinct images, flipped / rolled copies
+    out = []
+    for i in range(b):
+        g = base[i % 4]
+        if (i // 4) % 2:
+            g = g[:, ::-1]
+        out.append(np.roll(g, 7 * (i // 8), axis=0))
+    return torch.from_numpy(np.ascontiguousarray(np.stack(out)))
+
+
+@pytest.mark.parametrize("name,b,h,w,k,precision,oracle_images", [
+    ("cfg1_vga", 32, 480, 640, 1000, "fp32", 32),
+    ("cfg1_vga_f16", 32, 480, 640, 1000, "fp16", 8),
+    ("cfg2_720p", 64, 720, 1280, 2000, "fp32", 8),
+    ("cfg3_1080p_shard", 32, 1080, 1920, 2000, "fp32", 4),
+    ("cfg4_1080p_f16", 128, 1080, 1920, 2000, "fp16", 4),
+])
+def test_baseline_configuration(name, b, h, w, k, precision, oracle_images):
+    m = _model(precision)
+    imgs = _images(b, h, w).to(DEV)
+    with torch.inference_mode():
+        idx, score, count, prob = pipeline.detect_batch_u8(m, imgs, 15, 15, k)
+        torch.cuda.synchronize()
+    hp, wp, top, left = arch.padded_hw(h, w)
+    assert prob.shape == (b, hp, wp) and idx.shape == (b, k)
+    assert (count == k).all()                                           # >= K keypoints per image (north_star)
+    assert bool(torch.isfinite(prob).all())
+    # (i) NMS + top-K bit-exact on identical input, spread over the batch (first / last micro-batch included)
+    pick = np.unique(np.linspace(0, b - 1, oracle_images).astype(int))
+    for i in pick:
+        p = np.ascontiguousarray(prob[i, top:top + h, left:left + w].cpu().numpy())
+        ri, rs, _ = c_oracle.nms_topk(p, 15, 15, k)                     # raster order
+        ri, rs = oracle.canonical_order(ri.astype(np.int64), rs)        # the order the kernel emits
+        assert np.array_equal(idx[i].cpu().numpy(), ri.astype(np.int32)), (name, i)
+        assert np.array_equal(score[i].cpu().numpy().view(np.uint32), rs.view(np.uint32)), (name, i)
+    # (ii) batch invariance: the last image alone
+    with torch.inference_mode():
+        i1, s1, c1, p1 = pipeline.detect_batch_u8(m, imgs[b - 1:b].contiguous(), 15, 15, k)
+    assert torch.equal(p1[0], prob[b - 1]) and torch.equal(i1[0], idx[b - 1]) and torch.equal(s1[0], score[b - 1])
+    # (iv) score map of one image against the CPU oracle (fp32 torch ops), north_star tolerance 1e-4
+    if h <= 720:
+        g = imgs[1].cpu().numpy()
+        x = pipeline.pad_batch(synth.gray_to_rgb_norm(g)[None])
+        ref = oracle.detector_forward(synth.synthetic_state_dict(cases.WEIGHT_SEED), x)["prob"][0].numpy()
+        assert np.abs(prob[1].cpu().numpy() - ref).max() < 1e-4
