@@ -89,8 +89,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// In-kernel stamps (diagnostic build -DBALF_HN_STAMPS=1 only): thread 0 of every workgroup adds the cycles between
+// consecutive HSTAMP(i) points to g_hn_stamp[kernel][i]; balf_debug_hn_stamps() reads them back (tools/hn_stamps.py).
+#ifndef BALF_HN_STAMPS
+#define BALF_HN_STAMPS 0
+#endif
+#if BALF_HN_STAMPS
+__device__ unsigned long long g_hn_stamp[8][8];
+#define HSTAMP_DECL unsigned long long hs_prev = 0; (void)hs_prev
+#define HSTAMP(i)                                                                                       \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        unsigned long long hs_now;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hs_now)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if (threadIdx.x == 0) atomicAdd(&g_hn_stamp[Cfg::KID][(i)], (i) > 0 ? hs_now - hs_prev : 1ull);  \
+        hs_prev = hs_now;                                                                               \
+    } while (0)
+#else
+#define HSTAMP_DECL
+#define HSTAMP(i)
+#endif
+
 template <int CIN_, int COUT_, int HIN_, int STRIDE_, int OROWS_, bool FUSE1_>
 struct ConvCfg {
+    static constexpr int KID = FUSE1_ ? 0 : (CIN_ == 32 ? 1 : (CIN_ == 64 ? (STRIDE_ == 1 ? 2 : 3) : 4));
     static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, STRIDE = STRIDE_, OROWS = OROWS_;
     static constexpr bool FUSE1 = FUSE1_;
     static constexpr int HOUT = HIN / STRIDE, WP = HIN + 2, IR = (OROWS - 1) * STRIDE + 3;
@@ -102,6 +125,7 @@ struct ConvCfg {
     static constexpr int BANDS = HOUT / OROWS;
     static constexpr int INP_FLOATS = FUSE1 ? 34 * 34 : 0;
     static constexpr int LDS_BYTES = 2 * PLANE_BYTES + INP_FLOATS * 4 + 64;
+    static constexpr int OCC = FUSE1 ? 3 : 2;       // register-allocation target (workgroups per CU); measured
     static_assert(MG * NG == 4, "4 waves per workgroup");
     static_assert(HOUT % OROWS == 0 && NPIX % 64 == 0, "band shape");
 };
@@ -117,9 +141,9 @@ struct ConvArgs {
 };
 
 template <typename Cfg>
-__global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, HIN = Cfg::HIN, S = Cfg::STRIDE, HOUT = Cfg::HOUT, WP = Cfg::WP;
-    constexpr int WM = Cfg::WM, WN = Cfg::WN, MT = Cfg::MT, CH = Cfg::CH, KPT = Cfg::KPT;
+    constexpr int WM = Cfg::WM, WN = Cfg::WN, MT = Cfg::MT, CH = Cfg::CH, KPT = Cfg::KPT, IR = Cfg::IR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *act = smem;                                       // [plane][q][CIN] halves, chunk-swizzled
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,6 +151,8 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
     const int patch = blockIdx.x / Cfg::BANDS, band = blockIdx.x % Cfg::BANDS;
     const int r0 = band * Cfg::OROWS;                       // first output row
     const int r_in0 = r0 * S - 1;                           // input row of LDS row 0
+    HSTAMP_DECL;
+    HSTAMP(0);
 
     if constexpr (Cfg::FUSE1) {
         // ---- patch normalisation (hardnet_pytorch.py:58-63) ----
@@ -148,6 +174,7 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) inp[(py + 1) * 34 + px + 1 + j] = d[j] / sd;
         __syncthreads();
+        HSTAMP(1);      // patch load + normalisation
 
         // ---- conv1 + BN + ReLU for the band's 10 x 34 pixel frame, straight into the LDS image ----
         HL a1[2];
@@ -156,6 +183,9 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
             a1[m].hi = *reinterpret_cast<const h8 *>(a.w1 + (m * 2 + 0) * 1024 + lane * 16);
             a1[m].lo = *reinterpret_cast<const h8 *>(a.w1 + (m * 2 + 1) * 1024 + lane * 16);
         }
+        f4 bias1[2];                                    // loaded once: hipcc leaves a load written inside the
+#pragma unroll                                          // tile loop there, and every tile then pays an L2 round trip
+        for (int m = 0; m < 2; ++m) bias1[m] = *reinterpret_cast<const f4 *>(a.bias1 + 16 * m + 4 * g);
         constexpr int NQT = (Cfg::NQ + 15) / 16;
         for (int t = wave; t < NQT; t += 4) {
             const int q = 16 * t + n;
@@ -184,7 +214,7 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
             for (int m = 0; m < 2; ++m) {
                 f4 c = {0.0f, 0.0f, 0.0f, 0.0f};
                 c = mfma16x3(a1[m], b, c);
-                const f4 bb = *reinterpret_cast<const f4 *>(a.bias1 + 16 * m + 4 * g);
+                const f4 bb = bias1[m];
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = inside ? fmaxf(c[r] + bb[r], 0.0f) : 0.0f;
@@ -203,33 +233,42 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
         }
     } else {
         // ---- copy the input band (both planes) into the swizzled LDS image, zero frame included ----
-        // All global loads are issued before the first LDS write, so a workgroup pays one HBM round trip.
+        // An image row of one plane is 128 16-byte chunks in every layer (HIN * CIN / 8), so the 256 threads take
+        // two rows per pass and all index arithmetic is shifts and masks.  All global loads are issued before the
+        // first LDS write, so a workgroup pays one HBM round trip.
+        static_assert(HIN * CH == 128, "one image row of one plane = 128 chunks");
         const _Float16 *in = static_cast<const _Float16 *>(a.in) + (size_t)patch * 2 * HIN * HIN * CIN;
-        constexpr int TOTAL = 2 * Cfg::NQ * CH, ITERS = (TOTAL + 255) / 256;
-        h8 stage[ITERS];
+        constexpr int ROWS = 2 * IR, PASSES = (ROWS + 1) / 2;
+        const int rsub = tid >> 7, xc = tid & 127;              // row within the pass, chunk within the row
+        const int x = xc / CH, c = xc % CH;
+        h8 stage[PASSES];
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int i = tid + 256 * it;
-            const int plane = i / (Cfg::NQ * CH);
-            const int rem = i - plane * (Cfg::NQ * CH);
-            const int q = rem / CH, c = rem - q * CH;
-            const int iy = q / WP, ixp = q - iy * WP;
-            const int y = r_in0 + iy, x = ixp - 1;
-            stage[it] = zero8();
-            if (i < TOTAL && y >= 0 && y < HIN && x >= 0 && x < HIN)
-                stage[it] = *reinterpret_cast<const h8 *>(in + ((size_t)(plane * HIN + y) * HIN + x) * CIN + c * 8);
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = 2 * ps + rsub;                      // plane * IR + iy
+            const int plane = row >= IR ? 1 : 0;
+            const int y = r_in0 + row - plane * IR;
+            stage[ps] = zero8();
+            if (row < ROWS && y >= 0 && y < HIN)
+                stage[ps] = *reinterpret_cast<const h8 *>(in + ((size_t)(plane * HIN + y) * HIN) * CIN + xc * 8);
         }
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int i = tid + 256 * it;
-            const int plane = i / (Cfg::NQ * CH);
-            const int rem = i - plane * (Cfg::NQ * CH);
-            const int q = rem / CH, c = rem - q * CH;
-            if (i < TOTAL)
-                *reinterpret_cast<h8 *>(act + plane * Cfg::PLANE_BYTES + q * (CIN * 2) + ((c ^ swz<CH>(q)) << 4)) = stage[it];
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = 2 * ps + rsub;
+            const int plane = row >= IR ? 1 : 0;
+            const int q = (row - plane * IR) * WP + x + 1;
+            if (row < ROWS)
+                *reinterpret_cast<h8 *>(act + plane * Cfg::PLANE_BYTES + q * (CIN * 2) + ((c ^ swz<CH>(q)) << 4)) = stage[ps];
+        }
+        // the two frame columns (the frame rows, if any, were written as zeros above)
+        for (int i = tid; i < ROWS * 2 * CH; i += 256) {
+            const int row = i / (2 * CH), e = i % (2 * CH);
+            const int plane = row >= IR ? 1 : 0;
+            const int q = (row - plane * IR) * WP + (e >= CH ? WP - 1 : 0);
+            *reinterpret_cast<h8 *>(act + plane * Cfg::PLANE_BYTES + q * (CIN * 2) + (((e % CH) ^ swz<CH>(q)) << 4)) = zero8();
         }
     }
     __syncthreads();
+    HSTAMP(2);          // conv1 into LDS (fused kernel) / band load
 
     // ---- implicit GEMM over 9 taps x CIN ----
     const int mg = wave / Cfg::NG, ng = wave % Cfg::NG;
@@ -246,6 +285,9 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
 #pragma unroll
         for (int t = 0; t < WN; ++t) acc[m][t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
 
+    f4 bias[WM];                                        // requested before the K loop, used after it
+#pragma unroll
+    for (int m = 0; m < WM; ++m) bias[m] = *reinterpret_cast<const f4 *>(a.bias + 16 * (mg * WM + m) + 4 * g);
     const char *wl = a.w + (size_t)(mg * WM) * 2048 + lane * 16;
     auto load_a = [&](int ks, HL (&dst)[WM]) {
 #pragma unroll
@@ -261,43 +303,49 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
 #pragma unroll
         for (int t = 0; t < WN; ++t) {
             const int q = q0[t] + ky * WP + kx;
+#ifdef BALF_HN_ABLATE_BANK
+            const int off = ((q * (CIN * 2)) & ~1023) + lane * 16;      // timing experiment: conflict-free, wrong data
+#else
             const int off = q * (CIN * 2) + (((kk * 4 + g) ^ swz<CH>(q)) << 4);
+#endif
             dst[t].hi = *reinterpret_cast<const h8 *>(act + off);
             dst[t].lo = *reinterpret_cast<const h8 *>(act + Cfg::PLANE_BYTES + off);
         }
     };
-    HL abuf[2][WM], bbuf[2][WN];
+    // weights (global, L2 latency) run two K-steps ahead, LDS fragments one
+    HL abuf[3][WM], bbuf[2][WN];
     load_a(0, abuf[0]);
+    if (Cfg::KS > 1) load_a(1, abuf[1]);
     load_b(0, bbuf[0]);
 #pragma unroll
     for (int ks = 0; ks < Cfg::KS; ++ks) {
         const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < Cfg::KS) {
-            load_a(ks + 1, abuf[nxt]);
-            load_b(ks + 1, bbuf[nxt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch distance at exactly one K-step
+        const int ac = ks % 3;
+        if (ks + 2 < Cfg::KS) load_a(ks + 2, abuf[(ks + 2) % 3]);
+        if (ks + 1 < Cfg::KS) load_b(ks + 1, bbuf[nxt]);
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch distances exact
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[cur][m].lo, bbuf[cur][t].hi, acc[m][t]);
+            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[ac][m].lo, bbuf[cur][t].hi, acc[m][t]);
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[cur][m].hi, bbuf[cur][t].lo, acc[m][t]);
+            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[ac][m].hi, bbuf[cur][t].lo, acc[m][t]);
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[cur][m].hi, bbuf[cur][t].hi, acc[m][t]);
+            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[ac][m].hi, bbuf[cur][t].hi, acc[m][t]);
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    HSTAMP(3);          // K loop
     // ---- bias (folded BatchNorm) + ReLU, split, store both planes ----
     _Float16 *out = static_cast<_Float16 *>(a.out) + (size_t)patch * 2 * HOUT * HOUT * COUT;
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         const int co = 16 * (mg * WM + m) + 4 * g;
-        const f4 bb = *reinterpret_cast<const f4 *>(a.bias + co);
+        const f4 bb = bias[m];
 #pragma unroll
         for (int t = 0; t < WN; ++t) {
             const int p = 16 * (ng * WN + t) + n;
@@ -316,6 +364,7 @@ __global__ __launch_bounds__(256) void hn_conv_kernel(ConvArgs a) {
             *reinterpret_cast<h4 *>(out + (size_t)HOUT * HOUT * COUT + e) = lv;
         }
     }
+    HSTAMP(4);          // epilogue
 }
 
 // The last layer: out[co][patch] = sum_k W7[co][k] a6[patch][k], k = (y*8 + x)*128 + c -- exactly the order a6 is
@@ -495,6 +544,16 @@ void pack_layer(char *blob, int l, const float *w, const float *mean, const floa
 }  // namespace balf
 
 using namespace balf;
+
+#if BALF_HN_STAMPS
+extern "C" int balf_debug_hn_stamps(unsigned long long *out, int reset) {
+    if (reset) {
+        static unsigned long long z[64];
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_hn_stamp), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hn_stamp), 64 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int balf_hardnet_num_state_tensors(void) { return (int)hn_table().size(); }
 
