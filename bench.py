@@ -111,17 +111,23 @@ def cpu_baseline(h, w, k, n_images, state, threads=0):
     imgs = np.stack([synth.gray_to_rgb_norm(synth.synthetic_gray_u8(h, w, i)) for i in range(n_images)])
     t0 = time.perf_counter()
     kp = 0
+    t_fwd = t_nms = 0.0
     with torch.no_grad():
         for i in range(n_images):
+            ta = time.perf_counter()
             pad = O.mod_padding_symmetric(O.make_shape_even(imgs[i]), 64)
             x = torch.tensor(pad, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0)
             prob = O.detector_forward(state, x)["prob"][0].numpy()
+            tb = time.perf_counter()
             top, left = O.crop_offsets(h, w, *prob.shape)
             idx, sc, _ = c_oracle.nms_topk(prob[top:top + h, left:left + w], 15, 15, k)
+            t_nms += time.perf_counter() - tb
+            t_fwd += tb - ta
             kp += idx.size
     dt = time.perf_counter() - t0
     return {"value": n_images / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "keypoints_per_s": kp / dt,
+            "forward_s_per_image": t_fwd / n_images, "nms_topk_s_per_image": t_nms / n_images,
             "sample": f"{n_images} synthetic {w}x{h} gray images, batch 1, oracle forward (torch CPU fp32) + C NMS/top-{k}; "
                       f"{dt:.1f} s"}
 
