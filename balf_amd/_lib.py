@@ -98,3 +98,12 @@ def require_gpu_tensor(t, name: str) -> None:
 def current_stream_ptr(device) -> int:
     import torch
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def tensor_key(t):
+    """(storage address, version) of a parameter/buffer, for the packed-weight caches.  Inference tensors
+    (a model moved under torch.inference_mode()) do not track versions and cannot be modified in place."""
+    try:
+        return (t.data_ptr(), t._version)
+    except RuntimeError:
+        return (t.data_ptr(), -1)

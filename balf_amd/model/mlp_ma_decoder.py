@@ -90,7 +90,7 @@ class MLP_MA_DECODER(nn.Module):
 
     def _state_key(self, device):
         return (str(device), self.precision,
-                tuple((t.data_ptr(), t._version) for t in self.state_dict().values()))
+                tuple(_lib.tensor_key(t) for t in self.state_dict().values()))
 
     def packed_weights(self, device) -> torch.Tensor:
         key = self._state_key(device)

@@ -82,3 +82,13 @@ def test_rejects_bad_input(hardnet):
         hardnet(torch.zeros(2, 1, 31, 32, device="cuda:0"))
     with pytest.raises(BalfHipError):
         hardnet(torch.zeros(2, 1, 32, 32))
+
+
+def test_model_moved_under_inference_mode():
+    """Parameters created by .to() inside torch.inference_mode() are inference tensors (no version counter)."""
+    m = HardNet()
+    m.load_state_dict(synth.synthetic_hardnet_state_dict(cases.HARDNET_SEED))
+    x = synth.synthetic_patches(4, 1)
+    with torch.inference_mode():
+        d = m.eval().to("cuda:0")(x.to("cuda:0"))
+    assert d.shape == (4, 128)
