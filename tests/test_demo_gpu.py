@@ -119,3 +119,34 @@ def test_detect_mirror_shape(models):
     g = synth.synthetic_gray_u8(120, 160, 2)
     pts = demo_match.detect(demo_match.DEFAULT_ARGS, np.stack([g] * 3, -1), det, DEV)
     assert pts.ndim == 2 and pts.shape[1] == 3 and (pts[:, 2] == 1.0).all()
+
+
+def test_demo_main_sequence(tmp_path):
+    """The statements of the reference's demo ``__main__`` (demo/demo_match.py:120-147) with balf_amd's modules
+    swapped in: checkpoints on disk, get_model loaders, HardNet.load_state_dict(checkpoint['state_dict'])."""
+    from balf_amd.utils import test_utils
+    det_ckpt, hn_ckpt = tmp_path / "balf.pth", tmp_path / "HardNet++.pth"
+    torch.save({"epoch": 3, "repeatability": 0.7, "model_state": synth.synthetic_state_dict(cases.WEIGHT_SEED)}, det_ckpt)
+    torch.save({"state_dict": synth.synthetic_hardnet_state_dict(cases.HARDNET_SEED)}, hn_ckpt)
+    device = torch.device("cuda")
+    cfg = {"model": arch.DEFAULT_MODEL_CFG}
+    detector = get_model.load_model(cfg["model"])
+    epoch, rep = get_model.load_test_pretrained_model(model=detector, filename=str(det_ckpt))
+    assert (epoch, rep) == (3, 0.7)
+    detector = detector.eval().to(device)
+    descriptor = HardNet()
+    checkpoint_descriptor = torch.load(str(hn_ckpt), weights_only=True)
+    descriptor.load_state_dict(checkpoint_descriptor["state_dict"])
+    descriptor = descriptor.eval().to(device)
+    g1 = synth.synthetic_gray_u8(200, 264, 21, blur=7)
+    g2 = synth.synthetic_gray_u8(200, 264, 22, blur=7)
+    m1, m2 = demo_match.extract_matches(demo_match.DEFAULT_ARGS, np.stack([g1] * 3, -1), g1, np.stack([g2] * 3, -1), g2,
+                                        detector, descriptor, device)
+    assert m1.shape == m2.shape and m1.shape[1] == 2 and m1.dtype == np.float64
+    assert (m1[:, 0] >= 0).all() and (m1[:, 0] <= 263).all() and (m1[:, 1] >= 0).all() and (m1[:, 1] <= 199).all()
+    # and the reference's own post-processing helpers on a score map, as demo_match.detect uses them
+    with torch.inference_mode():
+        prob = detector(torch.zeros(1, 3, 256, 320, device=device))["prob"][0].cpu().numpy()
+    pts = test_utils.get_points_direct_from_score_map(heatmap=test_utils.remove_borders(prob, borders=15), conf_thresh=0.001,
+                                                      nms_size=15, subpixel=True, patch_size=4, order_coord="xysr")
+    assert pts.ndim == 2 and pts.shape[1] == 4
