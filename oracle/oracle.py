@@ -456,3 +456,15 @@ def apply_homography_to_points(points, h):
     tmp = pts[:, 2] ** 2 + np.finfo(np.float32).eps
     rad = np.sqrt(tmp * np.abs(fxdx * fydy - fxdy * fydx))
     return np.stack([nx / den, ny / den, rad, pts[:, 3]], axis=1)
+
+
+def compute_repeatability_with_maximum_filter(src_scores, dst_scores, homography, mask_src, mask_dst, nms_size, num_points):
+    """/root/reference/balf/utils/train_utils.py:170-196 from the pieces above."""
+    pts = []
+    for score, mask in ((src_scores, mask_src), (dst_scores, mask_dst)):
+        nms = np.multiply(apply_nms(np.asarray(score), nms_size), mask)
+        idx, sc = select_topk(nms, num_points)                       # raster order, like argwhere
+        pts.append(points_xysr(idx, sc, nms.shape[1]))
+    r = compute_repeatability(pts[0], apply_homography_to_points(pts[1], homography))
+    return ([r["rep_single_scale"]], [r["rep_multi_scale"]], [r["error_overlap_single_scale"]],
+            [r["error_overlap_multi_scale"]], [r["possible_matches"]])

@@ -128,3 +128,27 @@ def repeat_inputs(spec):
 
 
 HOMOGRAPHY = np.array([[1.05, 0.08, -12.0], [-0.06, 0.97, 9.0], [1.2e-4, -0.8e-4, 1.0]])
+
+
+# evaluation glue (train_utils.compute_repeatability_with_maximum_filter): two smooth score maps related by HOMOGRAPHY
+EVAL_CASE = dict(h=240, w=320, seed=31, nms=15, num_points=300)
+
+
+def eval_inputs(spec):
+    """(src score map, dst score map, mask_src, mask_dst): dst is src resampled through HOMOGRAPHY (nearest
+    neighbour) plus noise; the masks are rectangles standing in for the reference's cv2.warpPerspective masks."""
+    h, w = spec["h"], spec["w"]
+    rng = np.random.default_rng(500 + spec["seed"])
+    g = rng.random((h // 8 + 2, w // 8 + 2))
+    src = np.kron(g, np.ones((8, 8)))[:h, :w] * 0.5 + rng.random((h, w)) * 0.5
+    hinv = np.linalg.inv(HOMOGRAPHY)
+    ys, xs = np.mgrid[0:h, 0:w]
+    # pixel (x, y) of dst shows the src pixel HOMOGRAPHY maps it to (HOMOGRAPHY = dst -> src)
+    p = HOMOGRAPHY @ np.stack([xs.ravel(), ys.ravel(), np.ones(h * w)])
+    sx = np.clip(np.rint(p[0] / p[2]), 0, w - 1).astype(int)
+    sy = np.clip(np.rint(p[1] / p[2]), 0, h - 1).astype(int)
+    dst = src[sy, sx].reshape(h, w) * 0.97 + rng.random((h, w)) * 0.03
+    mask_src = np.zeros((h, w)); mask_src[20:h - 20, 25:w - 25] = 1.0
+    mask_dst = np.zeros((h, w)); mask_dst[22:h - 18, 20:w - 30] = 1.0
+    del hinv
+    return src.astype(np.float32), dst.astype(np.float32), mask_src, mask_dst

@@ -182,6 +182,20 @@ def main():
             rp[f"{name}.{k_}"] = np.asarray(v_)
     src, _ = cases.repeat_inputs(cases.REPEAT_CASES["small"])
     rp["homography.points"] = gt["apply_homography_to_points"](src, cases.HOMOGRAPHY)
+    # the evaluation glue around them (train_utils.py:170-196), also executed from the reference's source
+    import types
+    from scipy.ndimage import maximum_filter
+    rt2 = ref_functions("/root/reference/balf/benchmark_test/repeatability_tools.py",
+                        ["compute_repeatability", "intersection_area", "union_area", "apply_nms"],
+                        {"maximum_filter": maximum_filter})
+    gt2 = ref_functions("/root/reference/balf/benchmark_test/geometry_tools.py",
+                        ["apply_homography_to_points", "getAff", "get_point_coordinates", "find_index_higher_scores"])
+    tu = ref_functions("/root/reference/balf/utils/train_utils.py", ["compute_repeatability_with_maximum_filter"],
+                       {"repeatability_tools": types.SimpleNamespace(**rt2), "geometry_tools": types.SimpleNamespace(**gt2)})
+    es, ed, ms, md = cases.eval_inputs(cases.EVAL_CASE)
+    res = tu["compute_repeatability_with_maximum_filter"](es, ed, cases.HOMOGRAPHY, ms, md, cases.EVAL_CASE["nms"],
+                                                          cases.EVAL_CASE["num_points"])
+    rp["eval.result"] = np.asarray([float(np.asarray(v[0])) for v in res])
     np.savez_compressed(os.path.join(HERE, "repeatability.npz"), **rp)
 
     # ---------------- geometry, state-dict table, loader behaviour ----------------

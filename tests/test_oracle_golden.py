@@ -181,3 +181,11 @@ def test_homography_oracle_matches_reference_golden():
     g = np.load(os.path.join(G, "repeatability.npz"))
     src, _ = cases.repeat_inputs(cases.REPEAT_CASES["small"])
     assert np.abs(O.apply_homography_to_points(src, cases.HOMOGRAPHY) - g["homography.points"]).max() < 1e-11
+
+
+def test_evaluation_glue_oracle_matches_reference_golden():
+    g = np.load(os.path.join(G, "repeatability.npz"))
+    es, ed, ms, md = cases.eval_inputs(cases.EVAL_CASE)
+    res = O.compute_repeatability_with_maximum_filter(es, ed, cases.HOMOGRAPHY, ms, md, cases.EVAL_CASE["nms"],
+                                                      cases.EVAL_CASE["num_points"])
+    assert np.allclose([float(np.asarray(v[0])) for v in res], g["eval.result"], rtol=0, atol=1e-12)

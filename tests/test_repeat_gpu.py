@@ -63,3 +63,15 @@ def test_apply_homography_matches_reference_golden():
     src, _ = cases.repeat_inputs(cases.REPEAT_CASES["small"])
     out = geometry_tools.apply_homography_to_points(src, cases.HOMOGRAPHY)
     assert np.abs(out - g["homography.points"]).max() < 1e-11
+
+
+def test_evaluation_glue_matches_reference_golden():
+    """train_utils.compute_repeatability_with_maximum_filter end to end on the GPU (window-max NMS, masks, top-K
+    points, homography, repeatability) against the result recorded from the reference's own function bodies."""
+    from balf_amd.utils import train_utils
+    g = np.load(os.path.join(HERE, "golden", "repeatability.npz"))
+    es, ed, ms, md = cases.eval_inputs(cases.EVAL_CASE)
+    res = train_utils.compute_repeatability_with_maximum_filter(es, ed, cases.HOMOGRAPHY, ms, md, cases.EVAL_CASE["nms"],
+                                                                cases.EVAL_CASE["num_points"])
+    assert len(res) == 5 and all(isinstance(v, list) and len(v) == 1 for v in res)
+    assert np.allclose([float(np.asarray(v[0])) for v in res], g["eval.result"], rtol=0, atol=1e-12)
