@@ -61,3 +61,18 @@ def compute_repeatability(src_indexes, dst_indexes, overlap_err=0.4, eps=1e-6, d
             'num_points_multi_scale': found[1], 'error_overlap_single_scale': err_s,
             'error_overlap_multi_scale': err_m, 'total_num_points': points,
             'correspondences': corr[0], 'possible_matches': possible, 'correspondences_m': corr[1]}
+
+
+def check_common_points(kpts, mask):
+    """Indices of the key points (rows ``[y, x, ...]``) that fall inside ``mask`` (repeatability_tools.py:8-13; index
+    bookkeeping on the host, like the reference: note its off-by-one ``mask[round(y) - 1, round(x) - 1]``)."""
+    kpts = np.asarray(kpts)
+    if len(kpts) == 0:
+        return np.asarray([])
+    r = np.rint(kpts[:, :2]).astype(np.int64) - 1
+    return np.flatnonzero(np.asarray(mask)[r[:, 0], r[:, 1]] != 0)
+
+
+def select_top_k(kpts, k=1000):
+    """Indices of the ``k`` highest-scoring rows (score in column 3; repeatability_tools.py:15-17)."""
+    return np.argsort(-1 * np.asarray(kpts)[:, 3])[:k]

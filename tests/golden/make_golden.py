@@ -196,6 +196,11 @@ def main():
     res = tu["compute_repeatability_with_maximum_filter"](es, ed, cases.HOMOGRAPHY, ms, md, cases.EVAL_CASE["nms"],
                                                           cases.EVAL_CASE["num_points"])
     rp["eval.result"] = np.asarray([float(np.asarray(v[0])) for v in res])
+    hl = ref_functions("/root/reference/balf/benchmark_test/repeatability_tools.py", ["check_common_points", "select_top_k"])
+    src, _ = cases.repeat_inputs(cases.REPEAT_CASES["train_eval"])
+    kp = np.stack([src[:, 1] * 0.3 + 1, src[:, 0] * 0.3 + 1, src[:, 2], src[:, 3]], axis=1)      # rows [y, x, s, score]
+    rp["helpers.common"] = hl["check_common_points"](kp, ms)
+    rp["helpers.topk"] = hl["select_top_k"](kp, 40)
     np.savez_compressed(os.path.join(HERE, "repeatability.npz"), **rp)
 
     # ---------------- geometry, state-dict table, loader behaviour ----------------

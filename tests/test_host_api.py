@@ -177,3 +177,17 @@ def test_demo_match_mirror_signatures():
         "args", "im_rgb1", "im_gray1", "im_rgb2", "im_gray2", "detector", "descriptor", "device"]
     a = demo_match.DEFAULT_ARGS          # /root/reference/balf/configs/config.py:44-59
     assert (a.border_size, a.nms_size, a.num_features, a.s_mult, a.patch_size) == (15, 15, 2048, 60, 4)
+
+
+def test_repeatability_host_helpers_match_reference_golden():
+    """check_common_points / select_top_k (index bookkeeping, host side) against results recorded from the
+    reference's own function bodies."""
+    import numpy as np
+    from balf_amd.benchmark_test import repeatability_tools as R
+    from tests.golden import cases
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "repeatability.npz"))
+    src, _ = cases.repeat_inputs(cases.REPEAT_CASES["train_eval"])
+    _, _, ms, _ = cases.eval_inputs(cases.EVAL_CASE)
+    kp = np.stack([src[:, 1] * 0.3 + 1, src[:, 0] * 0.3 + 1, src[:, 2], src[:, 3]], axis=1)
+    assert np.array_equal(R.check_common_points(kp, ms), g["helpers.common"])
+    assert np.array_equal(R.select_top_k(kp, 40), g["helpers.topk"])
