@@ -54,3 +54,30 @@ def test_mirror_function():
     assert pts.dtype == np.float64 and pts.shape == (f[name + ".idx"].size, 4)
     assert np.array_equal((pts[:, 1] * spec["w"] + pts[:, 0]).astype(np.int32), f[name + ".idx"])
     assert T.get_points_direct_from_score_map(np.zeros((64, 64), np.float32), conf_thresh=0.001).shape == (0, 4)
+
+
+def test_greedy_random_sweep_vs_oracle():
+    """40 seeded random maps (odd sizes, thresholds, suppression radii 1..16, ties from quantisation) through
+    balf_greedy_nms against the oracle's sequential nms_fast restatement: same points, same order, same score bits."""
+    import torch
+    from balf_amd import ops
+    rng = np.random.default_rng(4242)
+    for case in range(40):
+        h, w = int(rng.integers(8, 90)), int(rng.integers(8, 110))
+        dist = int(rng.integers(1, 17))
+        border = int(rng.integers(0, 6))
+        conf = float(rng.choice([0.001, 0.015, 0.2, 0.6]))
+        m = rng.random((h, w), dtype=np.float32)
+        if case % 3 == 1:
+            m = (np.round(m * 20) / 20).astype(np.float32)
+        if case % 5 == 2:
+            m = np.where(rng.random((h, w)) < 0.05, m, 0.0).astype(np.float32)
+        rb = O.remove_borders(m, border)
+        ri, rs = O.greedy_nms(rb, conf, dist)
+        k = h * w
+        idx, sc, xy, cnt, tot = ops.greedy_nms(torch.from_numpy(m).cuda().unsqueeze(0), 0, 0, h, w, border, conf, dist, k, 0)
+        n = int(cnt[0])
+        tag = (case, h, w, dist, border, conf)
+        assert n == len(ri) == int(tot[0]), tag
+        assert np.array_equal(idx[0, :n].cpu().numpy(), np.asarray(ri, np.int32)), tag
+        assert np.array_equal(sc[0, :n].cpu().numpy().view(np.uint32), np.asarray(rs, np.float32).view(np.uint32)), tag

@@ -149,3 +149,44 @@ def test_test_utils_mirror(dev):
     assert pts.dtype == np.float64 and pts.shape == (spec["k"], 4)
     assert np.array_equal(pts[:, 3].astype(np.float32).view(np.uint32), f[name + ".score"].view(np.uint32))
     assert np.all(pts[:, 2] == 1.0)
+
+
+def test_random_sweep_vs_c_oracle(dev):
+    """120 seeded random configurations -- odd sizes down to 1 x 1, every window size, borders that swallow the whole
+    map, K from 1 to H*W, tie-heavy / sparse / zero maps, batches with crops -- bit-exact against the C oracle."""
+    from balf_amd import ops
+    from oracle import c_oracle
+    rng = np.random.default_rng(777)
+    for case in range(120):
+        h, w = int(rng.integers(1, 161)), int(rng.integers(1, 201))
+        size = int(rng.integers(1, 33))
+        border = int(rng.integers(0, 24))
+        k = int(rng.integers(1, min(h * w, 3000) + 1))
+        b = int(rng.integers(1, 4))
+        pad_t, pad_l = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+        hp, wp = h + pad_t + int(rng.integers(0, 9)), w + pad_l + int(rng.integers(0, 9))
+        kind = rng.choice(["rand", "quant", "quant8", "sparse", "zeros"])
+        maps = []
+        for i in range(b):
+            r = rng.random((hp, wp), dtype=np.float32)
+            if kind == "quant":
+                r = np.round(r * 50) / 50
+            elif kind == "quant8":
+                r = np.round(r * 4) / 4
+            elif kind == "sparse":
+                r = np.where(rng.random((hp, wp)) < 0.02, r + 0.01, 0.0)
+            elif kind == "zeros":
+                r = np.zeros((hp, wp))
+            maps.append(r.astype(np.float32))
+        t = torch.from_numpy(np.stack(maps)).to(dev)
+        idx, sc, cnt = ops.nms_topk(t, pad_t, pad_l, h, w, border, size, k)
+        idx, sc, cnt = idx.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(b):
+            ri, rs, _ = c_oracle.nms_topk(np.ascontiguousarray(maps[i][pad_t:pad_t + h, pad_l:pad_l + w]), border, size, k)
+            ri, rs = O.canonical_order(ri.astype(np.int64), rs)
+            n = int(cnt[i])
+            tag = (case, h, w, size, border, k, kind, i)
+            assert n == ri.size, tag
+            assert np.array_equal(idx[i, :n], ri.astype(np.int32)), tag
+            assert np.array_equal(sc[i, :n].view(np.uint32), rs.view(np.uint32)), tag
+            assert np.all(idx[i, n:] == -1), tag
