@@ -206,3 +206,28 @@ def test_error_behaviour(model):
         model(torch.zeros((1, 3, 100, 128), device="cuda:0"))
     with pytest.raises(BalfHipError):
         model(torch.zeros((1, 3, 64, 64)))
+
+
+def test_random_shapes_vs_oracle_and_uint8_identity(model, model16):
+    """10 seeded random image sizes (odd, tiny, wide, tall; gray and RGB; batch 1..3): uint8 input is bit-identical to
+    the host-prepared float input on both paths, and both score maps stay within the north-star tolerance of the CPU
+    oracle (fp32 torch ops) on the same padded input."""
+    from balf_amd import pipeline
+    sd = synth.synthetic_state_dict(cases.WEIGHT_SEED)
+    rng = np.random.default_rng(99)
+    for case in range(10):
+        h, w = int(rng.integers(1, 300)), int(rng.integers(1, 400))
+        b = int(rng.integers(1, 4))
+        rgb = bool(case % 2)
+        img = rng.integers(0, 256, size=(b, h, w, 3) if rgb else (b, h, w), dtype=np.uint8)
+        norm = img.astype(np.float64) / 255.0
+        if not rgb:
+            norm = np.stack([norm] * 3, axis=-1)
+        x = pipeline.pad_batch(norm)
+        ref = O.detector_forward(sd, x)["prob"].numpy()
+        for m, tol in ((model, 5e-6), (model16, 3e-5)):
+            with torch.inference_mode():
+                a = m(x.to("cuda:0"), want_logits=False)["prob"]
+                u = m.forward_u8(torch.from_numpy(img).to("cuda:0"), want_logits=False)["prob"]
+            assert torch.equal(a, u), (case, h, w, rgb)
+            assert np.abs(a.cpu().numpy() - ref).max() < tol, (case, h, w, rgb, m.precision)
