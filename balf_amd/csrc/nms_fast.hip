@@ -12,8 +12,9 @@
 // reference's order among exactly equal scores is whatever NumPy's unstable argsort produces.
 //
 // Kernels: greedy_init (crop + border + threshold -> key map), greedy_keep (LDS-tiled separable window max of
-// the 64-bit keys), greedy_kill (window OR of the newly-kept flags, alive count), greedy_collect (kept pixels ->
-// survivor list), then the top-K / sort kernel of nms_topk.hip and the optional sub-pixel soft-argmax.
+// the 64-bit keys), greedy_kill (window OR of the newly-kept flags, alive count per tile; newly kept points are
+// appended to the survivor list here), then the top-K / sort kernel of nms_topk.hip and the optional sub-pixel
+// soft-argmax.  Tiles without alive candidates are skipped by both passes, so the long tail of rounds is cheap.
 #include "common.h"
 #include "prof.h"
 
@@ -34,9 +35,12 @@ struct GreedyArgs {
     int d;                        // dist_thresh
     u64 *key;                     // [B, H, W]  (score bits << 32 | ~idx) while alive, 0 otherwise
     unsigned char *newk;          // [B, H, W]  kept in the current round
-    unsigned char *kept;          // [B, H, W]
+    int2 *surv;                   // [B, cap] kept points (flat index, score bits), appended as they are kept
+    int *counts;                  // [B]
     int *alive;                   // [1] alive candidates left (written by the last round of a group)
     int count_alive;
+    const int *tile_in;           // [B, tiles]  alive candidates per 32x32 tile before this round
+    int *tile_out;                // [B, tiles]  ... after it (written by the kill pass)
 };
 
 __device__ __forceinline__ float g_score(const GreedyArgs &a, const float *img, int y, int x) {
@@ -52,7 +56,6 @@ __global__ __launch_bounds__(GTHREADS) void greedy_init_kernel(GreedyArgs a) {
         const int y = (int)(i / a.W), x = (int)(i - (long)y * a.W);
         const float v = g_score(a, img, y, x);
         a.key[b * hw + i] = (v >= a.conf) ? (((u64)__float_as_uint(v) << 32) | (u64)(0xffffffffu - (unsigned)i)) : 0ull;
-        a.kept[b * hw + i] = 0;
     }
 }
 
@@ -64,6 +67,15 @@ __global__ __launch_bounds__(GTHREADS) void greedy_keep_kernel(GreedyArgs a) {
     const int b = blockIdx.z, ty0 = blockIdx.y * GT, tx0 = blockIdx.x * GT;
     const long hw = (long)a.H * a.W;
     const u64 *key = a.key + b * hw;
+    // a tile without alive candidates keeps nobody: after the first rounds that is almost every tile, and the long
+    // tail of rounds (a dozen on real score maps) costs a few bytes per tile instead of a window max
+    if (a.tile_in[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] == 0) {
+        for (int i = threadIdx.x; i < GT * GT; i += GTHREADS) {
+            const int y = ty0 + i / GT, x = tx0 + i % GT;
+            if (y < a.H && x < a.W) a.newk[b * hw + (long)y * a.W + x] = 0;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < side * side; i += GTHREADS) {
         const int r = i / side, c = i - r * side;
         const int y = ty0 - d + r, x = tx0 - d + c;
@@ -97,6 +109,11 @@ __global__ __launch_bounds__(GTHREADS) void greedy_kill_kernel(GreedyArgs a) {
     const int b = blockIdx.z, ty0 = blockIdx.y * GT, tx0 = blockIdx.x * GT;
     const long hw = (long)a.H * a.W;
     const unsigned char *nk = a.newk + b * hw;
+    const long tile = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (a.tile_in[tile] == 0) {                       // nobody alive here: nothing to kill, nothing newly kept
+        if (threadIdx.x == 0) a.tile_out[tile] = 0;
+        return;
+    }
     if (threadIdx.x == 0) s_cnt = 0;
     for (int i = threadIdx.x; i < side * side; i += GTHREADS) {
         const int r = i / side, c = i - r * side;
@@ -119,29 +136,21 @@ __global__ __launch_bounds__(GTHREADS) void greedy_kill_kernel(GreedyArgs a) {
         unsigned char m = 0;
         for (int k = 0; k <= 2 * d; ++k) m |= s_row[(r + k) * GT + c];
         const long p = b * hw + (long)y * a.W + x;
-        if (s_in[(r + d) * (S + 4) + c + d]) a.kept[p] = 1;
-        if (a.key[p] != 0ull) {
+        const u64 k = a.key[p];
+        if (s_in[(r + d) * (S + 4) + c + d]) {                  // newly kept: straight onto the survivor list
+            const int pos = atomicAdd(&a.counts[b], 1);
+            a.surv[b * hw + pos] = make_int2(y * a.W + x, (int)(k >> 32));
+        }
+        if (k != 0ull) {
             if (m) a.key[p] = 0ull;            // newly kept itself, or suppressed by a newly kept neighbour
             else ++alive;
         }
     }
-    if (a.count_alive) {
-        if (alive) atomicAdd(&s_cnt, alive);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_cnt) atomicAdd(a.alive, s_cnt);
-    }
-}
-
-__global__ __launch_bounds__(GTHREADS) void greedy_collect_kernel(GreedyArgs a, int2 *surv, int *counts, long cap) {
-    const long hw = (long)a.H * a.W;
-    const int b = blockIdx.y;
-    const float *img = a.src + (long)b * a.Hs * a.Ws;
-    for (long i = (long)blockIdx.x * GTHREADS + threadIdx.x; i < hw; i += (long)gridDim.x * GTHREADS) {
-        if (a.kept[b * hw + i]) {
-            const int y = (int)(i / a.W), x = (int)(i - (long)y * a.W);
-            const int pos = atomicAdd(&counts[b], 1);
-            surv[b * cap + pos] = make_int2((int)i, __float_as_int(g_score(a, img, y, x)));
-        }
+    if (alive) atomicAdd(&s_cnt, alive);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.tile_out[tile] = s_cnt;
+        if (a.count_alive && s_cnt) atomicAdd(a.alive, s_cnt);
     }
 }
 
@@ -176,8 +185,9 @@ __global__ void subpixel_kernel(GreedyArgs a, const int32_t *idx, const int32_t 
 extern "C" size_t balf_greedy_nms_workspace_bytes(int B, int H, int W, int K) {
     if (B <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
     const size_t px = (size_t)B * H * W;
-    return balf_align_up(px * 8, 256) + 2 * balf_align_up(px, 256) + 256 /*alive*/ +
-           balf_align_up((size_t)B * sizeof(int), 256) + px * sizeof(int2);
+    const size_t tiles = (size_t)B * balf_ceil_div(W, GT) * balf_ceil_div(H, GT);
+    return balf_align_up(px * 8, 256) + balf_align_up(px, 256) + 256 /*alive*/ +
+           balf_align_up((size_t)B * sizeof(int), 256) + 2 * balf_align_up(tiles * sizeof(int), 256) + px * sizeof(int2);
 }
 
 extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W,
@@ -196,12 +206,17 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
     char *w = static_cast<char *>(workspace_dev);
     u64 *key = reinterpret_cast<u64 *>(w); w += balf_align_up(px * 8, 256);
     unsigned char *newk = reinterpret_cast<unsigned char *>(w); w += balf_align_up(px, 256);
-    unsigned char *kept = reinterpret_cast<unsigned char *>(w); w += balf_align_up(px, 256);
     int *alive = reinterpret_cast<int *>(w); w += 256;
     int *counts = reinterpret_cast<int *>(w); w += balf_align_up((size_t)B * sizeof(int), 256);
+    const size_t n_tiles = (size_t)B * balf_ceil_div(W, GT) * balf_ceil_div(H, GT);
+    int *tile_a = reinterpret_cast<int *>(w); w += balf_align_up(n_tiles * sizeof(int), 256);
+    int *tile_b = reinterpret_cast<int *>(w); w += balf_align_up(n_tiles * sizeof(int), 256);
     int2 *surv = reinterpret_cast<int2 *>(w);
 
-    GreedyArgs a{prob_dev, Hp, Wp, crop_y, crop_x, H, W, border, conf_thresh, dist_thresh, key, newk, kept, alive, 0};
+    GreedyArgs a{prob_dev, Hp, Wp, crop_y, crop_x, H, W, border, conf_thresh, dist_thresh, key, newk, surv, counts,
+                 alive, 0, tile_a, tile_b};
+    if (hipMemsetAsync(counts, 0, balf_align_up((size_t)B * sizeof(int), 256), st) != hipSuccess) return BALF_ERR_LAUNCH;
+    if (hipMemsetAsync(tile_a, 1, n_tiles * sizeof(int), st) != hipSuccess) return BALF_ERR_LAUNCH;   // every tile may be alive
     const dim3 lin((unsigned)balf_ceil_div((long)H * W, GTHREADS * 4), B), tiles(balf_ceil_div(W, GT), balf_ceil_div(H, GT), B);
     hipLaunchKernelGGL(greedy_init_kernel, lin, dim3(GTHREADS), 0, st, a);
     BALF_LAUNCH_CHECK();
@@ -212,8 +227,9 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
         if (hipMemsetAsync(alive, 0, sizeof(int), st) != hipSuccess) return BALF_ERR_LAUNCH;
         for (int r = 0; r < 4; ++r) {
             a.count_alive = (r == 3);
-            hipLaunchKernelGGL(greedy_keep_kernel, tiles, dim3(GTHREADS), 0, st, a);
-            hipLaunchKernelGGL(greedy_kill_kernel, tiles, dim3(GTHREADS), 0, st, a);
+            BALF_PROF(balf_prof::kGreedyKeep, st, hipLaunchKernelGGL(greedy_keep_kernel, tiles, dim3(GTHREADS), 0, st, a));
+            BALF_PROF(balf_prof::kGreedyKill, st, hipLaunchKernelGGL(greedy_kill_kernel, tiles, dim3(GTHREADS), 0, st, a));
+            int *t = const_cast<int *>(a.tile_in); a.tile_in = a.tile_out; a.tile_out = t;   // ping-pong the tile counts
         }
         BALF_LAUNCH_CHECK();
         int h_alive = 0;
@@ -222,9 +238,6 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
             return BALF_ERR_LAUNCH;
         if (h_alive == 0) break;
     }
-    if (hipMemsetAsync(counts, 0, balf_align_up((size_t)B * sizeof(int), 256), st) != hipSuccess) return BALF_ERR_LAUNCH;
-    hipLaunchKernelGGL(greedy_collect_kernel, lin, dim3(GTHREADS), 0, st, a, surv, counts, (long)H * W);
-    BALF_LAUNCH_CHECK();
     if (total_dev && hipMemcpyAsync(total_dev, counts, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return BALF_ERR_LAUNCH;
     // the K best kept points by score, sorted (score desc, index asc); count_dev = rows returned (<= K)

@@ -37,6 +37,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void pyrdown_kernel(const T *in, int h, int w, float *out, int ho, int wo) {
     const int ox = blockIdx.x * 16 + (threadIdx.x & 15), oy = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (ox >= wo || oy >= ho) return;
+    in += (size_t)blockIdx.z * h * w;                       // image of the batch
+    out += (size_t)blockIdx.z * ho * wo;
     const float sy = fmaxf(((float)h / (float)ho) * ((float)oy + 0.5f) - 0.5f, 0.0f);
     const float sx = fmaxf(((float)w / (float)wo) * ((float)ox + 0.5f) - 0.5f, 0.0f);
     const int y0 = (int)sy, x0 = (int)sx;
@@ -61,17 +63,24 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(const T *in, int h, int w,
 struct SampleArgs {
     const void *img;            // level image: uint8 (level 0) or float
     int h, w;                   // level size
-    const float *xy;            // [N][2] level-0 pixel coordinates
-    float *patches;             // [N][32][32]
-    int n;
+    const float *xy;            // [B][K][2] level-0 pixel coordinates
+    float *patches;             // [B][K][32][32]
+    const int *count;           // [B] valid keypoints per image (nullptr: all K)
+    int n;                      // K
     float s_l;                  // LAF scale at this level
     float xs, ys;               // level-0 -> level coordinate factors  (w_l - 1)/(w_0 - 1), (h_l - 1)/(h_0 - 1)
 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
-    const int p = blockIdx.x;
-    const T *img = static_cast<const T *>(a.img);
+    const int b = blockIdx.y;
+    const size_t p = (size_t)b * a.n + blockIdx.x;
+    if (a.count && (int)blockIdx.x >= a.count[b]) {         // slot past the image's keypoint count: a zero patch
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a.patches[p * (kPS * kPS) + threadIdx.x + 256 * e] = 0.0f;
+        return;
+    }
+    const T *img = static_cast<const T *>(a.img) + (size_t)b * a.h * a.w;
     const float xc = a.xy[2 * p] * a.xs, yc = a.xy[2 * p + 1] * a.ys;
     const float wl1 = (float)(a.w - 1), hl1 = (float)(a.h - 1);
 #pragma unroll
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         const int x1 = x0 + 1 < a.w ? x0 + 1 : x0, y1 = y0 + 1 < a.h ? y0 + 1 : y0;     // weight is 0 when clamped
         const float v00 = px<T>(img, y0 * a.w + x0), v01 = px<T>(img, y0 * a.w + x1);
         const float v10 = px<T>(img, y1 * a.w + x0), v11 = px<T>(img, y1 * a.w + x1);
-        a.patches[(size_t)p * (kPS * kPS) + i] =
+        a.patches[p * (kPS * kPS) + i] =
             (1.0f - ly) * (1.0f - lx) * v00 + (1.0f - ly) * lx * v01 + ly * (1.0f - lx) * v10 + ly * lx * v11;
     }
 }
@@ -107,24 +116,24 @@ int pyramid_level(int h, int w, float scale) {
 
 using namespace balf;
 
-extern "C" size_t balf_extract_patches_workspace_bytes(int H, int W, float scale) {
-    if (H <= 0 || W <= 0 || !(scale > 0.0f)) return 0;
+extern "C" size_t balf_extract_patches_batch_workspace_bytes(int B, int H, int W, float scale) {
+    if (B <= 0 || H <= 0 || W <= 0 || !(scale > 0.0f)) return 0;
     const int level = pyramid_level(H, W, scale);
     size_t bytes = 256;
     int h = H, w = W;
     for (int l = 0; l < level && h >= kPS && w >= kPS; ++l) {
         h /= 2; w /= 2;
-        bytes += balf_align_up((size_t)h * w * 4, 256);
+        bytes += balf_align_up((size_t)B * h * w * 4, 256);
     }
     return bytes;
 }
 
-extern "C" int balf_extract_patches(const unsigned char *gray_dev, int H, int W, const float *xy_dev, int n_points,
-                                    float scale, float *patches_dev, void *workspace_dev, size_t workspace_bytes,
-                                    void *stream) {
-    if (!gray_dev || !xy_dev || !patches_dev || !workspace_dev || n_points <= 0 || !(scale > 0.0f)) return BALF_ERR_ARG;
-    if (H < 2 || W < 2) return BALF_ERR_SHAPE;
-    if (workspace_bytes < balf_extract_patches_workspace_bytes(H, W, scale)) return BALF_ERR_WORKSPACE;
+extern "C" int balf_extract_patches_batch(const unsigned char *gray_dev, int B, int H, int W, const float *xy_dev,
+                                          const int32_t *count_dev, int K, float scale, float *patches_dev,
+                                          void *workspace_dev, size_t workspace_bytes, void *stream) {
+    if (!gray_dev || !xy_dev || !patches_dev || !workspace_dev || B <= 0 || K <= 0 || !(scale > 0.0f)) return BALF_ERR_ARG;
+    if (H < 2 || W < 2 || B > 65535) return BALF_ERR_SHAPE;
+    if (workspace_bytes < balf_extract_patches_batch_workspace_bytes(B, H, W, scale)) return BALF_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int level = pyramid_level(H, W, scale);
     const void *cur = gray_dev;
@@ -133,7 +142,7 @@ extern "C" int balf_extract_patches(const unsigned char *gray_dev, int H, int W,
     for (int l = 0; l < level && h >= kPS && w >= kPS; ++l) {
         const int ho = h / 2, wo = w / 2;
         float *out = reinterpret_cast<float *>(ws);
-        const dim3 grid(balf_ceil_div(wo, 16), balf_ceil_div(ho, 16));
+        const dim3 grid(balf_ceil_div(wo, 16), balf_ceil_div(ho, 16), B);
         if (made == 0)
             BALF_PROF(balf_prof::kPatchPyr, st,
                       (pyrdown_kernel<unsigned char><<<grid, 256, 0, st>>>(gray_dev, h, w, out, ho, wo)));
@@ -141,16 +150,28 @@ extern "C" int balf_extract_patches(const unsigned char *gray_dev, int H, int W,
             BALF_PROF(balf_prof::kPatchPyr, st,
                       (pyrdown_kernel<float><<<grid, 256, 0, st>>>(static_cast<const float *>(cur), h, w, out, ho, wo)));
         BALF_LAUNCH_CHECK();
-        ws += balf_align_up((size_t)ho * wo * 4, 256);
+        ws += balf_align_up((size_t)B * ho * wo * 4, 256);
         cur = out; h = ho; w = wo; ++made;
     }
     const float ms0 = (float)((H < W ? H : W) - 1), msl = (float)((h < w ? h : w) - 1);
-    SampleArgs a{cur, h, w, xy_dev, patches_dev, n_points, scale / ms0 * msl,
+    SampleArgs a{cur, h, w, xy_dev, patches_dev, count_dev, K, scale / ms0 * msl,
                  (float)(w - 1) / (float)(W - 1), (float)(h - 1) / (float)(H - 1)};
+    const dim3 grid(K, B);
     if (made == 0)
-        BALF_PROF(balf_prof::kPatchSample, st, (sample_kernel<unsigned char><<<n_points, 256, 0, st>>>(a)));
+        BALF_PROF(balf_prof::kPatchSample, st, (sample_kernel<unsigned char><<<grid, 256, 0, st>>>(a)));
     else
-        BALF_PROF(balf_prof::kPatchSample, st, (sample_kernel<float><<<n_points, 256, 0, st>>>(a)));
+        BALF_PROF(balf_prof::kPatchSample, st, (sample_kernel<float><<<grid, 256, 0, st>>>(a)));
     BALF_LAUNCH_CHECK();
     return BALF_OK;
+}
+
+extern "C" size_t balf_extract_patches_workspace_bytes(int H, int W, float scale) {
+    return balf_extract_patches_batch_workspace_bytes(1, H, W, scale);
+}
+
+extern "C" int balf_extract_patches(const unsigned char *gray_dev, int H, int W, const float *xy_dev, int n_points,
+                                    float scale, float *patches_dev, void *workspace_dev, size_t workspace_bytes,
+                                    void *stream) {
+    return balf_extract_patches_batch(gray_dev, 1, H, W, xy_dev, nullptr, n_points, scale, patches_dev, workspace_dev,
+                                      workspace_bytes, stream);
 }

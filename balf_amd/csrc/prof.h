@@ -19,7 +19,9 @@ enum Slot {
     kPatchSample = 25,
     kMatchNN = 26,
     kMatchMutual = 27,
-    kNumSlots = 28,
+    kGreedyKeep = 28,       // greedy NMS of the demo path
+    kGreedyKill = 29,
+    kNumSlots = 30,
 };
 extern bool g_on;
 void before(int slot, hipStream_t st);

@@ -49,7 +49,7 @@ static const char *kSlotNames[balf_prof::kNumSlots] = {
     "stage4_grid_branch", "stage4_block_branch", "stage4_se", "stage4_head",
     "nms_tile", "topk_select",
     "hardnet_conv1_2", "hardnet_conv3", "hardnet_conv4", "hardnet_conv5", "hardnet_conv6", "hardnet_fc",
-    "patch_pyrdown", "patch_sample", "match_nn", "match_mutual"};
+    "patch_pyrdown", "patch_sample", "match_nn", "match_mutual", "greedy_keep", "greedy_kill"};
 
 extern "C" int balf_profile_num_slots(void) { return balf_prof::kNumSlots; }
 

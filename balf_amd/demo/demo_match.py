@@ -46,6 +46,33 @@ def _detect_gpu(args, im: np.ndarray, detector, device) -> torch.Tensor:
     return torch.cat([pts, torch.ones((n, 1), device=device)], dim=1)
 
 
+def detect_and_describe_batch(args, images_u8: torch.Tensor, detector, descriptor, gray_u8: torch.Tensor = None):
+    """The feature half of the demo for a whole batch in one pass, nothing on the host: uint8 images on the GPU
+    (gray ``[B,H,W]`` or RGB ``[B,H,W,3]`` with their gray versions in ``gray_u8``) -> (xy [B,K,2] keypoints,
+    strongest first; descriptors [B,K,128]; count [B] valid rows per image), K = args.num_features.  Per image this
+    is what :func:`extract_features` returns (demo_match.py:59-95)."""
+    if args.order_coord != "xysr":
+        raise NotImplementedError("the demo path is implemented for order_coord='xysr' (the reference default)")
+    if gray_u8 is None:
+        if images_u8.dim() != 3:
+            raise ValueError("RGB input needs the gray images (PIL's convert('L'), demo_match.py:15-17) in gray_u8")
+        gray_u8 = images_u8
+    b, h, w = images_u8.shape[:3]
+    _, _, top, left = arch.padded_hw(h, w)
+    k = min(int(args.num_features), h * w)
+    with torch.inference_mode():
+        prob = detector.forward_u8(images_u8, want_logits=False)["prob"]
+        idx, score, xy, count, total = ops.greedy_nms(prob, top, left, h, w, args.border_size,
+                                                      args.heatmap_confidence_threshold, args.nms_size, k,
+                                                      args.patch_size if args.sub_pixel else 0)
+        if not args.sub_pixel:
+            ii = idx.long().clamp_(min=0)
+            xy = torch.stack([(ii % w).float(), (ii // w).float()], dim=2)
+        patches = ops.extract_patches_batch(gray_u8, xy, count, float(args.s_mult))
+        descs = descriptor(patches.view(b * k, 1, 32, 32)).view(b, k, 128)
+    return xy, descs, count
+
+
 def detect(args, im, detector, device):
     """demo_match.py:21-57: image [H,W,3] uint8 -> keypoints [n,3] = (x, y, 1), strongest first."""
     pts = _detect_gpu(args, im, detector, device)

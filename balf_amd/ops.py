@@ -130,6 +130,32 @@ def extract_patches(gray_u8: torch.Tensor, xy: torch.Tensor, scale: float) -> to
     return out
 
 
+def extract_patches_batch(gray_u8: torch.Tensor, xy: torch.Tensor, count, scale: float) -> torch.Tensor:
+    """Batched :func:`extract_patches`: gray_u8 [B,H,W] uint8, xy [B,K,2], count [B] int32 (or None: all K valid) ->
+    patches [B,K,1,32,32]; slots past an image's count are zero patches (balf_extract_patches_batch)."""
+    require_gpu_tensor(gray_u8, "gray_u8")
+    if gray_u8.dtype != torch.uint8 or gray_u8.dim() != 3:
+        raise BalfHipError("gray_u8 must be a [B,H,W] uint8 tensor")
+    if xy.dim() != 3 or xy.shape[0] != gray_u8.shape[0] or xy.shape[2] != 2 or not xy.is_cuda:
+        raise BalfHipError("xy must be a [B,K,2] GPU tensor")
+    xy = xy.contiguous().float()
+    b, h, w = gray_u8.shape
+    k = xy.shape[1]
+    dev = gray_u8.device
+    out = torch.empty((b, k, 1, 32, 32), dtype=torch.float32, device=dev)
+    if k == 0:
+        return out
+    if count is not None:
+        count = count.to(device=dev, dtype=torch.int32).contiguous()
+    ws = _workspace("patches", dev, lib().balf_extract_patches_batch_workspace_bytes(b, h, w, float(scale)))
+    with torch.cuda.device(dev):
+        check(lib().balf_extract_patches_batch(gray_u8.data_ptr(), b, h, w, xy.data_ptr(),
+                                               count.data_ptr() if count is not None else None, k, float(scale),
+                                               out.data_ptr(), ws.data_ptr(), ws.numel(), current_stream_ptr(dev)),
+              "balf_extract_patches_batch")
+    return out
+
+
 def match_smnn(desc1: torch.Tensor, desc2: torch.Tensor, th: float = 0.8) -> Tuple[torch.Tensor, torch.Tensor]:
     """``kornia.feature.match_smnn(desc1, desc2, th)`` (/root/reference/demo/demo_match.py:104-110): returns
     (dists [M,1] fp32, idxs [M,2] int64), mutual ratio-test matches sorted by the index in ``desc1``."""

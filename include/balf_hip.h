@@ -149,6 +149,12 @@ int balf_hardnet_forward(const void *packed_dev, const float *patches_dev, int n
 size_t balf_extract_patches_workspace_bytes(int H, int W, float scale);
 int balf_extract_patches(const unsigned char *gray_dev, int H, int W, const float *xy_dev, int n_points, float scale,
                          float *patches_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+/* Batched form: gray_dev [B,H,W], xy_dev [B,K,2], count_dev [B] = keypoints actually present per image (NULL: all
+ * K; slots past the count get zero patches), patches_dev [B,K,32,32].  One pyramid per image, one launch for all. */
+size_t balf_extract_patches_batch_workspace_bytes(int B, int H, int W, float scale);
+int balf_extract_patches_batch(const unsigned char *gray_dev, int B, int H, int W, const float *xy_dev,
+                               const int32_t *count_dev, int K, float scale, float *patches_dev, void *workspace_dev,
+                               size_t workspace_bytes, void *stream);
 size_t balf_match_smnn_workspace_bytes(int n1, int n2);
 int balf_match_smnn(const float *desc1_dev, int n1, const float *desc2_dev, int n2, float th, int32_t *idx_dev,
                     float *dist_dev, int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream);

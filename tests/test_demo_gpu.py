@@ -150,3 +150,20 @@ def test_demo_main_sequence(tmp_path):
     pts = test_utils.get_points_direct_from_score_map(heatmap=test_utils.remove_borders(prob, borders=15), conf_thresh=0.001,
                                                       nms_size=15, subpixel=True, patch_size=4, order_coord="xysr")
     assert pts.ndim == 2 and pts.shape[1] == 4
+
+
+def test_batched_detect_and_describe_equals_per_image(models):
+    """One pass over a batch (detector, greedy NMS, patches, HardNet in single launches) gives, per image, exactly what
+    the per-image demo functions give."""
+    det, hn = models
+    args = demo_match.DEFAULT_ARGS
+    grays = [synth.synthetic_gray_u8(200, 264, 40 + i, blur=5 if i % 2 else 7) for i in range(3)]
+    batch = torch.from_numpy(np.stack(grays)).to(DEV)
+    xy, desc, count = demo_match.detect_and_describe_batch(args, batch, det, hn)
+    assert xy.shape[0] == desc.shape[0] == 3 and desc.shape[2] == 128
+    for i, g in enumerate(grays):
+        k1, d1 = demo_match.extract_features(args, np.stack([g] * 3, -1), g, det, hn, DEV)
+        n = int(count[i])
+        assert n == k1.shape[0]
+        assert np.array_equal(xy[i, :n].double().cpu().numpy(), k1)
+        assert np.array_equal(desc[i, :n].cpu().numpy(), d1)
