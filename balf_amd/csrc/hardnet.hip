@@ -138,7 +138,13 @@ struct ConvArgs {
     const char *w1;          // FUSE1: conv1 fragments + bias
     const float *bias1;
     int n_patches;
+    const int *count;        // optional mask: patch p (global index p0 + local) is used iff (p % group) < count[p / group]
+    int group, p0;
 };
+
+__device__ __forceinline__ bool hn_patch_used(const int *count, int group, int p) {
+    return count == nullptr || (p % group) < count[p / group];
+}
 
 template <typename Cfg>
 __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int patch = blockIdx.x / Cfg::BANDS, band = blockIdx.x % Cfg::BANDS;
+    if (!hn_patch_used(a.count, a.group, a.p0 + patch)) return;      // masked slot: no work, its buffers stay stale
     const int r0 = band * Cfg::OROWS;                       // first output row
     const int r_in0 = r0 * S - 1;                           // input row of LDS row 0
     HSTAMP_DECL;
@@ -377,6 +384,8 @@ struct FcArgs {
     const char *w;
     const float *bias;
     int n_patches;
+    const int *count;        // optional mask, as ConvArgs
+    int group;
 };
 
 constexpr int kFcStageKs = 2, kFcStageBytes = kFcStageKs * 8 * 2048, kFcLds = 2 * kFcStageBytes;
@@ -388,11 +397,26 @@ __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
     const int n = lane & 15, g = lane >> 4;
     const int p0 = blockIdx.x * 128 + wave * 32;
     const _Float16 *bp[WN];
+    bool used[WN];
+    int any = 0;
 #pragma unroll
     for (int t = 0; t < WN; ++t) {
         int p = p0 + 16 * t + n;
+        used[t] = p < a.n_patches && hn_patch_used(a.count, a.group, p);
+        any |= used[t];
         p = p < a.n_patches ? p : a.n_patches - 1;
         bp[t] = a.in + (size_t)p * 2 * kFcK + g * 8;
+    }
+    if (a.count != nullptr && !__syncthreads_or(any)) {      // a tile of masked slots: zero descriptors, no GEMM
+#pragma unroll
+        for (int t = 0; t < WN; ++t) {
+            const int p = p0 + 16 * t + n;
+            if (p < a.n_patches)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    *reinterpret_cast<f4 *>(a.desc + (size_t)p * kDesc + 16 * m + 4 * g) = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        return;
     }
     f4 acc[MT][WN];
 #pragma unroll
@@ -470,7 +494,7 @@ __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
         part[t] += __shfl_xor(part[t], 16);
         part[t] += __shfl_xor(part[t], 32);
         const int p = p0 + 16 * t + n;
-        const float inv = 1.0f / sqrtf(part[t] + 1e-10f);
+        const float inv = used[t] ? 1.0f / sqrtf(part[t] + 1e-10f) : 0.0f;        // masked slots: zero descriptors
         if (p < a.n_patches) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -587,9 +611,11 @@ extern "C" size_t balf_hardnet_workspace_bytes(int n_patches) {
     return c * (kBufA + kBufB) + (size_t)n_patches * kBufA6;
 }
 
-extern "C" int balf_hardnet_forward(const void *packed_dev, const float *patches_dev, int n_patches, float *desc_dev,
-                                    void *workspace_dev, size_t workspace_bytes, void *stream) {
+extern "C" int balf_hardnet_forward_masked(const void *packed_dev, const float *patches_dev, int n_patches, int group,
+                                           const int32_t *count_dev, float *desc_dev, void *workspace_dev,
+                                           size_t workspace_bytes, void *stream) {
     if (!packed_dev || !patches_dev || !desc_dev || !workspace_dev || n_patches <= 0) return BALF_ERR_ARG;
+    if (count_dev && (group <= 0 || n_patches % group != 0)) return BALF_ERR_ARG;
     if (workspace_bytes < balf_hardnet_workspace_bytes(n_patches)) return BALF_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const char *blob = static_cast<const char *>(packed_dev);
@@ -603,6 +629,7 @@ extern "C" int balf_hardnet_forward(const void *packed_dev, const float *patches
         int rc;
         ConvArgs a{};
         a.n_patches = n;
+        a.count = count_dev; a.group = group > 0 ? group : 1; a.p0 = c0;
         a.in = patches_dev + (size_t)c0 * kPS * kPS; a.out = bufA;
         a.w = blob + hn_woff(1); a.bias = bias(1); a.w1 = blob + hn_woff(0); a.bias1 = bias(0);
         if ((rc = launch_conv<CfgL2>(balf_prof::kHnConv2, a, st)) != BALF_OK) return rc;
@@ -616,8 +643,15 @@ extern "C" int balf_hardnet_forward(const void *packed_dev, const float *patches
         if ((rc = launch_conv<CfgL6>(balf_prof::kHnConv6, a, st)) != BALF_OK) return rc;
     }
     // the final GEMM runs once over the whole batch (a chunk alone would fill 32 of the 256 CUs)
-    FcArgs f{reinterpret_cast<const _Float16 *>(a6), desc_dev, blob + hn_woff(6), bias(6), n_patches};
+    FcArgs f{reinterpret_cast<const _Float16 *>(a6), desc_dev, blob + hn_woff(6), bias(6), n_patches, count_dev,
+             group > 0 ? group : 1};
     BALF_PROF(balf_prof::kHnFc, st, (hn_fc_kernel<<<balf_ceil_div(n_patches, 128), 256, kFcLds, st>>>(f)));
     BALF_LAUNCH_CHECK();
     return BALF_OK;
+}
+
+extern "C" int balf_hardnet_forward(const void *packed_dev, const float *patches_dev, int n_patches, float *desc_dev,
+                                    void *workspace_dev, size_t workspace_bytes, void *stream) {
+    return balf_hardnet_forward_masked(packed_dev, patches_dev, n_patches, 0, nullptr, desc_dev, workspace_dev,
+                                       workspace_bytes, stream);
 }

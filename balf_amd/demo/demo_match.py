@@ -69,7 +69,7 @@ def detect_and_describe_batch(args, images_u8: torch.Tensor, detector, descripto
             ii = idx.long().clamp_(min=0)
             xy = torch.stack([(ii % w).float(), (ii // w).float()], dim=2)
         patches = ops.extract_patches_batch(gray_u8, xy, count, float(args.s_mult))
-        descs = descriptor(patches.view(b * k, 1, 32, 32)).view(b, k, 128)
+        descs = descriptor.forward_slots(patches, count)          # unused slots: zero rows, no compute
     return xy, descs, count
 
 

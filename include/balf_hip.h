@@ -136,6 +136,12 @@ int balf_hardnet_pack_weights(const float *const *tensors, int n_tensors, void *
 size_t balf_hardnet_workspace_bytes(int n_patches);
 int balf_hardnet_forward(const void *packed_dev, const float *patches_dev, int n_patches, float *desc_dev,
                          void *workspace_dev, size_t workspace_bytes, void *stream);
+/* Masked form for fixed-size keypoint slots: the patches are n_patches / group images x `group` slots, and only the
+ * first count_dev[image] slots of each image are computed (the others cost nothing and get zero descriptors).
+ * count_dev == NULL: as balf_hardnet_forward. */
+int balf_hardnet_forward_masked(const void *packed_dev, const float *patches_dev, int n_patches, int group,
+                                const int32_t *count_dev, float *desc_dev, void *workspace_dev, size_t workspace_bytes,
+                                void *stream);
 
 /* ---- patch extraction and descriptor matching of the demo path -------------------------
  * balf_extract_patches replaces kornia.feature.laf_from_center_scale_ori + extract_patches_from_pyramid(PS=32) as
