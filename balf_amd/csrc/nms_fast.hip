@@ -34,7 +34,7 @@ struct GreedyArgs {
     float conf;
     int d;                        // dist_thresh
     u64 *key;                     // [B, H, W]  (score bits << 32 | ~idx) while alive, 0 otherwise
-    unsigned char *newk;          // [B, H, W]  kept in the current round
+    unsigned *newk;               // [B, H, ceil(W/32)] bit map: kept in the current round
     int2 *surv;                   // [B, cap] kept points (flat index, score bits), appended as they are kept
     int *counts;                  // [B]
     int *alive;                   // [1] alive candidates left (written by the last round of a group)
@@ -59,21 +59,52 @@ __global__ __launch_bounds__(GTHREADS) void greedy_init_kernel(GreedyArgs a) {
     }
 }
 
+__device__ __forceinline__ u64 umax64(u64 x, u64 y) { return x > y ? x : y; }
+
+// Window maxima of R consecutive outputs that share most of their inputs: out[j] = max(in[j .. j+w-1]), j = 0..R-1.
+// The w-R+1 inputs common to all R windows are reduced once; each output adds a running maximum from the left
+// remainder and one from the right remainder: ~(w + 3R) max operations for R outputs instead of R (w - 1).
+// Keys are unsigned and 0 means "dead", so 0 is the identity.
+template <int R, typename In, typename Out>
+__device__ __forceinline__ void window_max_run(int w, In in, Out out) {
+    if (w >= R) {
+        u64 core = in(R - 1);
+        for (int k = R; k < w; ++k) core = umax64(core, in(k));
+        u64 left[R], right[R];
+        u64 acc = 0ull;
+        left[R - 1] = 0ull;
+#pragma unroll
+        for (int j = R - 2; j >= 0; --j) { acc = umax64(acc, in(j)); left[j] = acc; }
+        acc = 0ull;
+        right[0] = 0ull;
+#pragma unroll
+        for (int j = 1; j < R; ++j) { acc = umax64(acc, in(w - 1 + j)); right[j] = acc; }
+#pragma unroll
+        for (int j = 0; j < R; ++j) out(j, umax64(core, umax64(left[j], right[j])));
+    } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            u64 m = in(j);
+            for (int k = 1; k < w; ++k) m = umax64(m, in(j + k));
+            out(j, m);
+        }
+    }
+}
+
+// newk is a bit map: word [b][y][tx] holds the "kept in this round" flags of pixels x = 32 tx .. 32 tx + 31 of row y
 __global__ __launch_bounds__(GTHREADS) void greedy_keep_kernel(GreedyArgs a) {
     constexpr int S = GT + 2 * GD_MAX;
     __shared__ u64 s_in[S * (S + 1)];
-    __shared__ u64 s_row[S * GT];
-    const int d = a.d, side = GT + 2 * d;
+    __shared__ u64 s_row[S * (GT + 1)];
+    const int d = a.d, side = GT + 2 * d, w = 2 * d + 1;
     const int b = blockIdx.z, ty0 = blockIdx.y * GT, tx0 = blockIdx.x * GT;
     const long hw = (long)a.H * a.W;
     const u64 *key = a.key + b * hw;
+    unsigned *bits = a.newk + ((long)b * a.H) * gridDim.x + blockIdx.x;       // + y * gridDim.x
     // a tile without alive candidates keeps nobody: after the first rounds that is almost every tile, and the long
     // tail of rounds (a dozen on real score maps) costs a few bytes per tile instead of a window max
     if (a.tile_in[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] == 0) {
-        for (int i = threadIdx.x; i < GT * GT; i += GTHREADS) {
-            const int y = ty0 + i / GT, x = tx0 + i % GT;
-            if (y < a.H && x < a.W) a.newk[b * hw + (long)y * a.W + x] = 0;
-        }
+        if (threadIdx.x < GT && ty0 + threadIdx.x < a.H) bits[(long)(ty0 + threadIdx.x) * gridDim.x] = 0u;
         return;
     }
     for (int i = threadIdx.x; i < side * side; i += GTHREADS) {
@@ -82,50 +113,61 @@ __global__ __launch_bounds__(GTHREADS) void greedy_keep_kernel(GreedyArgs a) {
         s_in[r * (S + 1) + c] = (y >= 0 && y < a.H && x >= 0 && x < a.W) ? key[(long)y * a.W + x] : 0ull;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < side * GT; i += GTHREADS) {          // row pass
-        const int r = i / GT, c = i - r * GT;
-        u64 m = s_in[r * (S + 1) + c];
-        for (int k = 1; k <= 2 * d; ++k) { const u64 v = s_in[r * (S + 1) + c + k]; m = v > m ? v : m; }
-        s_row[r * GT + c] = m;
+    for (int i = threadIdx.x; i < side * (GT / 8); i += GTHREADS) {        // row pass: 8 outputs per item
+        const int r = i / (GT / 8), c0 = (i - r * (GT / 8)) * 8;
+        const u64 *row = s_in + r * (S + 1) + c0;
+        window_max_run<8>(w, [&](int k) { return row[k]; }, [&](int j, u64 v) { s_row[r * (GT + 1) + c0 + j] = v; });
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < GT * GT; i += GTHREADS) {            // column pass + decision
-        const int r = i / GT, c = i - r * GT;
-        const int y = ty0 + r, x = tx0 + c;
-        if (y >= a.H || x >= a.W) continue;
-        u64 m = s_row[r * GT + c];
-        for (int k = 1; k <= 2 * d; ++k) { const u64 v = s_row[(r + k) * GT + c]; m = v > m ? v : m; }
-        const u64 own = s_in[(r + d) * (S + 1) + c + d];
-        a.newk[b * hw + (long)y * a.W + x] = (own != 0ull && own == m) ? 1 : 0;
+    {                                                                       // column pass: 4 outputs per item
+        const int c = threadIdx.x & (GT - 1), r0 = (threadIdx.x >> 5) * 4;  // 32 columns x 8 row groups of 4
+        const u64 *col = s_row + r0 * (GT + 1) + c;
+        unsigned keep4 = 0;
+        window_max_run<4>(w, [&](int k) { return col[k * (GT + 1)]; }, [&](int j, u64 m) {
+            const u64 own = s_in[(r0 + j + d) * (S + 1) + c + d];
+            if (own != 0ull && own == m) keep4 |= 1u << j;
+        });
+        // one word per row: bit c of row r0 + j = lane's flag j; the 32 lanes of a row group sit in one half wave
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long bal = __ballot((keep4 >> j) & 1u);
+            const unsigned word = (unsigned)((threadIdx.x & 32) ? (bal >> 32) : bal);
+            const int y = ty0 + r0 + j;
+            if (c == 0 && y < a.H) bits[(long)y * gridDim.x] = word;
+        }
     }
 }
 
 __global__ __launch_bounds__(GTHREADS) void greedy_kill_kernel(GreedyArgs a) {
     constexpr int S = GT + 2 * GD_MAX;
-    __shared__ unsigned char s_in[S * (S + 4)];
-    __shared__ unsigned char s_row[S * GT];
+    __shared__ u64 s_h[S];                          // per halo row: horizontal window-OR of the kept flags
+    __shared__ u64 s_own[S];
     __shared__ int s_cnt;
-    const int d = a.d, side = GT + 2 * d;
+    const int d = a.d, side = GT + 2 * d, w = 2 * d + 1;
     const int b = blockIdx.z, ty0 = blockIdx.y * GT, tx0 = blockIdx.x * GT;
     const long hw = (long)a.H * a.W;
-    const unsigned char *nk = a.newk + b * hw;
     const long tile = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (a.tile_in[tile] == 0) {                       // nobody alive here: nothing to kill, nothing newly kept
         if (threadIdx.x == 0) a.tile_out[tile] = 0;
         return;
     }
     if (threadIdx.x == 0) s_cnt = 0;
-    for (int i = threadIdx.x; i < side * side; i += GTHREADS) {
-        const int r = i / side, c = i - r * side;
-        const int y = ty0 - d + r, x = tx0 - d + c;
-        s_in[r * (S + 4) + c] = (y >= 0 && y < a.H && x >= 0 && x < a.W) ? nk[(long)y * a.W + x] : 0;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < side * GT; i += GTHREADS) {
-        const int r = i / GT, c = i - r * GT;
-        unsigned char m = 0;
-        for (int k = 0; k <= 2 * d; ++k) m |= s_in[r * (S + 4) + c + k];
-        s_row[r * GT + c] = m;
+    if (threadIdx.x < side) {
+        // bits x = tx0 - d .. tx0 + 31 + d of halo row r as one 64-bit word (bit k = column tx0 - d + k)
+        const int r = threadIdx.x, y = ty0 - d + r;
+        u64 m = 0ull;
+        if (y >= 0 && y < a.H) {
+            const unsigned *row = a.newk + ((long)b * a.H + y) * gridDim.x;
+            const int tx = blockIdx.x;
+            const u64 mid = row[tx];
+            const u64 lo = tx > 0 ? row[tx - 1] : 0u, hi = tx + 1 < (int)gridDim.x ? row[tx + 1] : 0u;
+            m = (d > 0 ? (lo >> (32 - d)) : 0ull) | (mid << d) | (d > 0 ? (hi << (32 + d)) : 0ull);
+        }
+        s_own[r] = m;
+        u64 t = m;                                    // horizontal OR over a window of w bits by doubling
+        int have = 1;
+        while (2 * have <= w) { t |= t >> have; have *= 2; }
+        s_h[r] = t | (t >> (w - have));               // bit k = OR of columns k .. k + w - 1
     }
     __syncthreads();
     int alive = 0;
@@ -133,18 +175,17 @@ __global__ __launch_bounds__(GTHREADS) void greedy_kill_kernel(GreedyArgs a) {
         const int r = i / GT, c = i - r * GT;
         const int y = ty0 + r, x = tx0 + c;
         if (y >= a.H || x >= a.W) continue;
-        unsigned char m = 0;
-        for (int k = 0; k <= 2 * d; ++k) m |= s_row[(r + k) * GT + c];
         const long p = b * hw + (long)y * a.W + x;
         const u64 k = a.key[p];
-        if (s_in[(r + d) * (S + 4) + c + d]) {                  // newly kept: straight onto the survivor list
+        if (k == 0ull) continue;
+        u64 v = 0ull;                                 // vertical OR of the rows r .. r + 2d (wave-uniform per row)
+        for (int q = 0; q < w; ++q) v |= s_h[r + q];
+        if ((s_own[r + d] >> (c + d)) & 1ull) {       // newly kept: straight onto the survivor list
             const int pos = atomicAdd(&a.counts[b], 1);
             a.surv[b * hw + pos] = make_int2(y * a.W + x, (int)(k >> 32));
         }
-        if (k != 0ull) {
-            if (m) a.key[p] = 0ull;            // newly kept itself, or suppressed by a newly kept neighbour
-            else ++alive;
-        }
+        if ((v >> c) & 1ull) a.key[p] = 0ull;         // newly kept itself, or suppressed by a newly kept neighbour
+        else ++alive;
     }
     if (alive) atomicAdd(&s_cnt, alive);
     __syncthreads();
@@ -186,7 +227,7 @@ extern "C" size_t balf_greedy_nms_workspace_bytes(int B, int H, int W, int K) {
     if (B <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
     const size_t px = (size_t)B * H * W;
     const size_t tiles = (size_t)B * balf_ceil_div(W, GT) * balf_ceil_div(H, GT);
-    return balf_align_up(px * 8, 256) + balf_align_up(px, 256) + 256 /*alive*/ +
+    return balf_align_up(px * 8, 256) + balf_align_up((size_t)B * H * balf_ceil_div(W, GT) * 4, 256) + 256 /*alive*/ +
            balf_align_up((size_t)B * sizeof(int), 256) + 2 * balf_align_up(tiles * sizeof(int), 256) + px * sizeof(int2);
 }
 
@@ -205,7 +246,7 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
     const size_t px = (size_t)B * H * W;
     char *w = static_cast<char *>(workspace_dev);
     u64 *key = reinterpret_cast<u64 *>(w); w += balf_align_up(px * 8, 256);
-    unsigned char *newk = reinterpret_cast<unsigned char *>(w); w += balf_align_up(px, 256);
+    unsigned *newk = reinterpret_cast<unsigned *>(w); w += balf_align_up((size_t)B * H * balf_ceil_div(W, GT) * 4, 256);
     int *alive = reinterpret_cast<int *>(w); w += 256;
     int *counts = reinterpret_cast<int *>(w); w += balf_align_up((size_t)B * sizeof(int), 256);
     const size_t n_tiles = (size_t)B * balf_ceil_div(W, GT) * balf_ceil_div(H, GT);
