@@ -50,6 +50,8 @@ PROTOTYPES = {
     "balf_extract_patches_batch": (_i, [_vp, _i, _i, _i, _fp, _vp, _i, C.c_float, _fp, _vp, _sz, _vp]),
     "balf_match_smnn_workspace_bytes": (_sz, [_i, _i]),
     "balf_match_smnn": (_i, [_fp, _i, _fp, _i, C.c_float, _vp, _fp, _vp, _vp, _sz, _vp]),
+    "balf_match_smnn_batch_workspace_bytes": (_sz, [_i, _i, _i]),
+    "balf_match_smnn_batch": (_i, [_fp, _i, _vp, _fp, _i, _vp, _i, C.c_float, _vp, _fp, _vp, _vp, _sz, _vp]),
     "balf_repeatability_workspace_bytes": (_sz, [_i, _i, _i]),
     "balf_repeatability": (_i, [_vp, _i, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_double, _i, _vp, _vp, _vp, _vp,
                                _vp, _sz, _vp]),

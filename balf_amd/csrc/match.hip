@@ -59,10 +59,18 @@ __device__ __forceinline__ float row_norm2(const f4 (&v)[8]) {
 }
 
 // nn_idx[i] = argmin_j |a_i - b_j|, nn_ratio[i] = d_first / d_second (NaN/inf when d_second = 0, as the reference)
-__global__ __launch_bounds__(64) void match_nn_kernel(const float *a, int na, const float *b, int nb, int *nn_idx,
-                                                      float *nn_ratio) {
+// Batched over blockIdx.y: pair p compares a + p*stride_a (na_dev[p] rows) with b + p*stride_b (nb_dev[p] rows);
+// na_dev / nb_dev == nullptr: one pair with the sizes passed by value.
+__global__ __launch_bounds__(64) void match_nn_kernel(const float *a, int na, const int *na_dev, long stride_a,
+                                                      const float *b, int nb, const int *nb_dev, long stride_b,
+                                                      int *nn_idx, float *nn_ratio, int out_stride) {
     const int lane = threadIdx.x, n = lane & 15, kq = lane >> 4;
+    const int pair = blockIdx.y;
+    if (na_dev) { na = na_dev[pair]; nb = nb_dev[pair]; }
+    a += pair * stride_a; b += pair * stride_b;
+    nn_idx += (long)pair * out_stride; nn_ratio += (long)pair * out_stride;
     const int row0 = blockIdx.x * 16;
+    if (row0 >= na || nb <= 0) return;
     f4 av[8];
     load_rows(a, row0 + n, na, kq, av);
     const float an = row_norm2(av);                 // |a|^2 of row (row0 + n), same in the 4 kq lanes
@@ -102,12 +110,19 @@ __global__ __launch_bounds__(64) void match_nn_kernel(const float *a, int na, co
     }
 }
 
-__global__ __launch_bounds__(1024) void match_mutual_kernel(const int *idx1, const float *ratio1, int n1, const int *idx2,
-                                                            const float *ratio2, int n2, float th, int *out_idx,
+__global__ __launch_bounds__(1024) void match_mutual_kernel(const int *idx1, const float *ratio1, int n1, const int *n1_dev,
+                                                            int stride1, const int *idx2, const float *ratio2, int n2,
+                                                            const int *n2_dev, int stride2, float th, int *out_idx,
                                                             float *out_dist, int *out_count, int cap) {
     __shared__ int wsum[16];
     __shared__ int base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = blockIdx.x;
+    if (n1_dev) { n1 = n1_dev[pair]; n2 = n2_dev[pair]; }
+    if (n1 < 2 || n2 < 2) th = -1.0f;       // the reference returns no matches when either side has < 2 descriptors
+    idx1 += (long)pair * stride1; ratio1 += (long)pair * stride1;
+    idx2 += (long)pair * stride2; ratio2 += (long)pair * stride2;
+    out_idx += (long)pair * cap * 2; out_dist += (long)pair * cap; out_count += pair;
     if (tid == 0) base = 0;
     __syncthreads();
     for (int i0 = 0; i0 < n1; i0 += 1024) {
@@ -154,9 +169,50 @@ __global__ __launch_bounds__(1024) void match_mutual_kernel(const int *idx1, con
 
 using namespace balf;
 
+extern "C" size_t balf_match_smnn_batch_workspace_bytes(int pairs, int k1, int k2) {
+    if (pairs <= 0 || k1 <= 0 || k2 <= 0) return 0;
+    return balf_align_up((size_t)pairs * k1 * 8, 256) + balf_align_up((size_t)pairs * k2 * 8, 256);
+}
+
+// pairs > 1 (or count pointers given): desc1 [pairs,k1,128], desc2 [pairs,k2,128] with n1_dev/n2_dev [pairs] valid rows
+static int match_launch(const float *d1, int k1, const int *n1_dev, const float *d2, int k2, const int *n2_dev, int pairs,
+                        float th, int32_t *idx_dev, float *dist_dev, int32_t *count_dev, void *workspace_dev,
+                        hipStream_t st) {
+    char *ws = static_cast<char *>(workspace_dev);
+    int *idx1 = reinterpret_cast<int *>(ws);
+    float *r1 = reinterpret_cast<float *>(ws + (size_t)pairs * k1 * 4);
+    char *ws2 = ws + balf_align_up((size_t)pairs * k1 * 8, 256);
+    int *idx2 = reinterpret_cast<int *>(ws2);
+    float *r2 = reinterpret_cast<float *>(ws2 + (size_t)pairs * k2 * 4);
+    BALF_PROF(balf_prof::kMatchNN, st,
+              (match_nn_kernel<<<dim3(balf_ceil_div(k1, 16), pairs), 64, 0, st>>>(d1, k1, n1_dev, (long)k1 * kD, d2, k2, n2_dev,
+                                                                                 (long)k2 * kD, idx1, r1, k1)));
+    BALF_LAUNCH_CHECK();
+    BALF_PROF(balf_prof::kMatchNN, st,
+              (match_nn_kernel<<<dim3(balf_ceil_div(k2, 16), pairs), 64, 0, st>>>(d2, k2, n2_dev, (long)k2 * kD, d1, k1, n1_dev,
+                                                                                 (long)k1 * kD, idx2, r2, k2)));
+    BALF_LAUNCH_CHECK();
+    const int cap = k1 < k2 ? k1 : k2;
+    BALF_PROF(balf_prof::kMatchMutual, st,
+              (match_mutual_kernel<<<pairs, 1024, 0, st>>>(idx1, r1, k1, n1_dev, k1, idx2, r2, k2, n2_dev, k2, th, idx_dev,
+                                                            dist_dev, count_dev, cap)));
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}
+
+extern "C" int balf_match_smnn_batch(const float *desc1_dev, int k1, const int32_t *n1_dev, const float *desc2_dev, int k2,
+                                     const int32_t *n2_dev, int pairs, float th, int32_t *idx_dev, float *dist_dev,
+                                     int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    if (!desc1_dev || !desc2_dev || !n1_dev || !n2_dev || !idx_dev || !dist_dev || !count_dev || !workspace_dev)
+        return BALF_ERR_ARG;
+    if (pairs <= 0 || pairs > 65535 || k1 <= 0 || k2 <= 0) return BALF_ERR_ARG;
+    if (workspace_bytes < balf_match_smnn_batch_workspace_bytes(pairs, k1, k2)) return BALF_ERR_WORKSPACE;
+    return match_launch(desc1_dev, k1, n1_dev, desc2_dev, k2, n2_dev, pairs, th, idx_dev, dist_dev, count_dev, workspace_dev,
+                        static_cast<hipStream_t>(stream));
+}
+
 extern "C" size_t balf_match_smnn_workspace_bytes(int n1, int n2) {
-    if (n1 <= 0 || n2 <= 0) return 0;
-    return balf_align_up((size_t)n1 * 8, 256) + balf_align_up((size_t)n2 * 8, 256);
+    return balf_match_smnn_batch_workspace_bytes(1, n1, n2);
 }
 
 extern "C" int balf_match_smnn(const float *desc1_dev, int n1, const float *desc2_dev, int n2, float th,
@@ -165,23 +221,6 @@ extern "C" int balf_match_smnn(const float *desc1_dev, int n1, const float *desc
     if (!desc1_dev || !desc2_dev || !idx_dev || !dist_dev || !count_dev || !workspace_dev || n1 <= 0 || n2 <= 0)
         return BALF_ERR_ARG;
     if (workspace_bytes < balf_match_smnn_workspace_bytes(n1, n2)) return BALF_ERR_WORKSPACE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    char *ws = static_cast<char *>(workspace_dev);
-    int *idx1 = reinterpret_cast<int *>(ws);
-    float *r1 = reinterpret_cast<float *>(ws + (size_t)n1 * 4);
-    char *ws2 = ws + balf_align_up((size_t)n1 * 8, 256);
-    int *idx2 = reinterpret_cast<int *>(ws2);
-    float *r2 = reinterpret_cast<float *>(ws2 + (size_t)n2 * 4);
-    BALF_PROF(balf_prof::kMatchNN, st,
-              (match_nn_kernel<<<balf_ceil_div(n1, 16), 64, 0, st>>>(desc1_dev, n1, desc2_dev, n2, idx1, r1)));
-    BALF_LAUNCH_CHECK();
-    BALF_PROF(balf_prof::kMatchNN, st,
-              (match_nn_kernel<<<balf_ceil_div(n2, 16), 64, 0, st>>>(desc2_dev, n2, desc1_dev, n1, idx2, r2)));
-    BALF_LAUNCH_CHECK();
-    const int cap = n1 < n2 ? n1 : n2;
-    if (n1 < 2 || n2 < 2) th = -1.0f;       // the reference returns no matches when either side has < 2 descriptors
-    BALF_PROF(balf_prof::kMatchMutual, st,
-              (match_mutual_kernel<<<1, 1024, 0, st>>>(idx1, r1, n1, idx2, r2, n2, th, idx_dev, dist_dev, count_dev, cap)));
-    BALF_LAUNCH_CHECK();
-    return BALF_OK;
+    return match_launch(desc1_dev, n1, nullptr, desc2_dev, n2, nullptr, 1, th, idx_dev, dist_dev, count_dev, workspace_dev,
+                        static_cast<hipStream_t>(stream));
 }

@@ -179,3 +179,30 @@ def match_smnn(desc1: torch.Tensor, desc2: torch.Tensor, th: float = 0.8) -> Tup
                                     current_stream_ptr(dev)), "balf_match_smnn")
     m = int(count.item())
     return dist[:m].view(-1, 1), idx[:m].long()
+
+
+def match_smnn_batch(desc1: torch.Tensor, n1: torch.Tensor, desc2: torch.Tensor, n2: torch.Tensor, th: float = 0.8):
+    """``pairs`` independent :func:`match_smnn` problems in three launches: desc1 [P,K1,128] / desc2 [P,K2,128] with
+    n1 / n2 [P] valid rows each -> (dist [P,cap] fp32, idx [P,cap,2] int32 (-1 padded), count [P] int32), cap =
+    min(K1, K2); nothing is read back to the host (balf_match_smnn_batch)."""
+    require_gpu_tensor(desc1, "desc1")
+    require_gpu_tensor(desc2, "desc2")
+    if desc1.dim() != 3 or desc2.dim() != 3 or desc1.shape[2] != 128 or desc2.shape[2] != 128 or desc1.shape[0] != desc2.shape[0]:
+        raise BalfHipError("descriptors must be [P,K,128] with the same number of pairs")
+    desc1, desc2 = desc1.float(), desc2.float()
+    p, k1, k2 = desc1.shape[0], desc1.shape[1], desc2.shape[1]
+    dev = desc1.device
+    cap = min(k1, k2)
+    idx = torch.empty((p, cap, 2), dtype=torch.int32, device=dev)
+    dist = torch.empty((p, cap), dtype=torch.float32, device=dev)
+    count = torch.empty((p,), dtype=torch.int32, device=dev)
+    if p == 0 or cap == 0:
+        return dist, idx, count.zero_()
+    n1 = n1.to(device=dev, dtype=torch.int32).contiguous()
+    n2 = n2.to(device=dev, dtype=torch.int32).contiguous()
+    ws = _workspace("match", dev, lib().balf_match_smnn_batch_workspace_bytes(p, k1, k2))
+    with torch.cuda.device(dev):
+        check(lib().balf_match_smnn_batch(desc1.data_ptr(), k1, n1.data_ptr(), desc2.data_ptr(), k2, n2.data_ptr(), p,
+                                          float(th), idx.data_ptr(), dist.data_ptr(), count.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), current_stream_ptr(dev)), "balf_match_smnn_batch")
+    return dist, idx, count

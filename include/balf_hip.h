@@ -162,6 +162,12 @@ int balf_extract_patches_batch(const unsigned char *gray_dev, int B, int H, int 
                                const int32_t *count_dev, int K, float scale, float *patches_dev, void *workspace_dev,
                                size_t workspace_bytes, void *stream);
 size_t balf_match_smnn_workspace_bytes(int n1, int n2);
+/* Batched form: `pairs` independent problems, desc1_dev [pairs,k1,128] / desc2_dev [pairs,k2,128] with n1_dev / n2_dev
+ * [pairs] valid rows each; idx_dev [pairs,min(k1,k2),2], dist_dev [pairs,min(k1,k2)], count_dev [pairs]. */
+size_t balf_match_smnn_batch_workspace_bytes(int pairs, int k1, int k2);
+int balf_match_smnn_batch(const float *desc1_dev, int k1, const int32_t *n1_dev, const float *desc2_dev, int k2,
+                          const int32_t *n2_dev, int pairs, float th, int32_t *idx_dev, float *dist_dev,
+                          int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 int balf_match_smnn(const float *desc1_dev, int n1, const float *desc2_dev, int n2, float th, int32_t *idx_dev,
                     float *dist_dev, int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 

@@ -167,3 +167,28 @@ def test_batched_detect_and_describe_equals_per_image(models):
         assert n == k1.shape[0]
         assert np.array_equal(xy[i, :n].double().cpu().numpy(), k1)
         assert np.array_equal(desc[i, :n].cpu().numpy(), d1)
+
+
+def test_match_smnn_batch_equals_per_pair():
+    rng = np.random.default_rng(8)
+    P, K = 5, 300
+    d1 = np.stack([_descs(K, 10 + i) for i in range(P)])
+    d2 = np.stack([_descs(K, 50 + i) for i in range(P)])
+    n1 = np.array([300, 257, 1, 64, 0], np.int32)
+    n2 = np.array([300, 300, 200, 2, 100], np.int32)
+    for i in range(P):                                    # plant correspondences inside the valid ranges
+        m = min(n1[i], n2[i]) // 2
+        if m:
+            noisy = d1[i, :m] + 0.1 * rng.standard_normal((m, 128)).astype(np.float32)
+            d2[i, n2[i] - m:n2[i]] = noisy / np.linalg.norm(noisy, axis=1, keepdims=True)
+    t1, t2 = torch.from_numpy(d1).to(DEV), torch.from_numpy(d2).to(DEV)
+    dist, idx, count = ops.match_smnn_batch(t1, torch.from_numpy(n1), t2, torch.from_numpy(n2), 0.95)
+    for i in range(P):
+        c = int(count[i])
+        if n1[i] == 0 or n2[i] == 0:
+            assert c == 0
+            continue
+        gd, gi = ops.match_smnn(t1[i, :n1[i]].contiguous(), t2[i, :n2[i]].contiguous(), 0.95)
+        assert c == gi.shape[0]
+        assert torch.equal(idx[i, :c].long(), gi) and torch.equal(dist[i, :c], gd.view(-1))
+        assert bool((idx[i, c:] == -1).all())

@@ -57,11 +57,24 @@ def main():
         _, ids = ops.match_smnn(desc[0, :n0], desc[1, :n1], 0.99)
     torch.cuda.synchronize()
     t_match = (time.perf_counter() - t1) / 20
+    # all consecutive image pairs of the batch in one batched call (16 pairs at batch 32)
+    half = b // 2
+    if half:
+        d1, d2 = desc[0::2][:half].contiguous(), desc[1::2][:half].contiguous()
+        c1, c2 = count[0::2][:half].contiguous(), count[1::2][:half].contiguous()
+        ops.match_smnn_batch(d1, c1, d2, c2, 0.99)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(10):
+            mdist, midx, mcount = ops.match_smnn_batch(d1, c1, d2, c2, 0.99)
+        torch.cuda.synchronize()
+        t_batch = (time.perf_counter() - t2) / 10
     kp = float(count.float().mean())
     print(json.dumps({"metric": "demo feature extraction (detect + describe), images/s", "value": b / dt, "unit": "images/s",
                       "batch": b, "image": f"{w}x{h} gray uint8", "ms_per_batch": dt * 1e3, "keypoints_per_image": kp,
                       "descriptors_per_s": b * kp / dt, "device_ms": groups,
                       "match_smnn_ms": t_match * 1e3, "match_pairs": [n0, n1], "matches": int(ids.shape[0]),
+                      "match_smnn_batch_ms": (t_batch * 1e3 if half else None), "match_batch_pairs": half,
                       "dtype": "split-f16 MFMA detector and descriptor, fp32 everything else"}))
 
 
