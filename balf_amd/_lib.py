@@ -44,6 +44,7 @@ PROTOTYPES = {
     "balf_hardnet_workspace_bytes": (_sz, [_i]),
     "balf_hardnet_forward": (_i, [_vp, _fp, _i, _fp, _vp, _sz, _vp]),
     "balf_hardnet_forward_masked": (_i, [_vp, _fp, _i, _i, _vp, _fp, _vp, _sz, _vp]),
+    "balf_hardnet_forward_ex": (_i, [_vp, _fp, _i, _i, _vp, _i, _fp, _vp, _sz, _vp]),
     "balf_extract_patches_workspace_bytes": (_sz, [_i, _i, C.c_float]),
     "balf_extract_patches": (_i, [_vp, _i, _i, _fp, _i, C.c_float, _fp, _vp, _sz, _vp]),
     "balf_extract_patches_batch_workspace_bytes": (_sz, [_i, _i, _i, C.c_float]),

@@ -77,6 +77,9 @@ __device__ __forceinline__ h8 zero8() {
     return z;
 }
 
+// plain-f16 mode: round to nearest (the split mode truncates hi and carries the rest in lo)
+__device__ __forceinline__ h2 round_pair(float v0, float v1) { return h2{(_Float16)v0, (_Float16)v1}; }
+
 template <int CH>
 __device__ __forceinline__ int swz(int q) {
     constexpr int SH = CH == 4 ? 2 : (CH == 8 ? 1 : 0);
@@ -111,8 +114,10 @@ __device__ unsigned long long g_hn_stamp[8][8];
 #define HSTAMP(i)
 #endif
 
-template <int CIN_, int COUT_, int HIN_, int STRIDE_, int OROWS_, bool FUSE1_>
+template <int CIN_, int COUT_, int HIN_, int STRIDE_, int OROWS_, bool FUSE1_, bool SPLIT_ = true>
 struct ConvCfg {
+    static constexpr bool SPLIT = SPLIT_;                   // false: plain f16 operands (hi plane only, one product)
+    static constexpr int NPL = SPLIT_ ? 2 : 1;              // activation planes
     static constexpr int KID = FUSE1_ ? 0 : (CIN_ == 32 ? 1 : (CIN_ == 64 ? (STRIDE_ == 1 ? 2 : 3) : 4));
     static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, STRIDE = STRIDE_, OROWS = OROWS_;
     static constexpr bool FUSE1 = FUSE1_;
@@ -124,7 +129,7 @@ struct ConvCfg {
     static constexpr int PLANE_BYTES = NQ * CIN * 2;
     static constexpr int BANDS = HOUT / OROWS;
     static constexpr int INP_FLOATS = FUSE1 ? 34 * 34 : 0;
-    static constexpr int LDS_BYTES = 2 * PLANE_BYTES + INP_FLOATS * 4 + 64;
+    static constexpr int LDS_BYTES = NPL * PLANE_BYTES + INP_FLOATS * 4 + 64;
     static constexpr int OCC = FUSE1 ? 3 : 2;       // register-allocation target (workgroups per CU); measured
     static_assert(MG * NG == 4, "4 waves per workgroup");
     static_assert(HOUT % OROWS == 0 && NPIX % 64 == 0, "band shape");
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
 
     if constexpr (Cfg::FUSE1) {
         // ---- patch normalisation (hardnet_pytorch.py:58-63) ----
-        float *inp = reinterpret_cast<float *>(smem + 2 * Cfg::PLANE_BYTES);        // [34][34], zero frame
+        float *inp = reinterpret_cast<float *>(smem + Cfg::NPL * Cfg::PLANE_BYTES); // [34][34], zero frame
         float *red = inp + 34 * 34;
         const float *src = static_cast<const float *>(a.in) + (size_t)patch * (kPS * kPS);
         const f4 v = *reinterpret_cast<const f4 *>(src + 4 * tid);
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             a1[m].hi = *reinterpret_cast<const h8 *>(a.w1 + (m * 2 + 0) * 1024 + lane * 16);
-            a1[m].lo = *reinterpret_cast<const h8 *>(a.w1 + (m * 2 + 1) * 1024 + lane * 16);
+            if constexpr (Cfg::SPLIT) a1[m].lo = *reinterpret_cast<const h8 *>(a.w1 + (m * 2 + 1) * 1024 + lane * 16);
         }
         f4 bias1[2];                                    // loaded once: hipcc leaves a load written inside the
 #pragma unroll                                          // tile loop there, and every tile then pays an L2 round trip
@@ -213,28 +218,30 @@ __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 h2 hh, ll;
-                split_pair(tv[2 * j], tv[2 * j + 1], hh, ll);
+                if constexpr (Cfg::SPLIT) split_pair(tv[2 * j], tv[2 * j + 1], hh, ll);
+                else { hh = round_pair(tv[2 * j], tv[2 * j + 1]); ll = hh; }
                 b.hi[2 * j] = hh[0]; b.hi[2 * j + 1] = hh[1];
                 b.lo[2 * j] = ll[0]; b.lo[2 * j + 1] = ll[1];
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 f4 c = {0.0f, 0.0f, 0.0f, 0.0f};
-                c = mfma16x3(a1[m], b, c);
+                if constexpr (Cfg::SPLIT) c = mfma16x3(a1[m], b, c);
+                else c = mfma16(a1[m].hi, b.hi, c);
                 const f4 bb = bias1[m];
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = inside ? fmaxf(c[r] + bb[r], 0.0f) : 0.0f;
                 h2 h01, l01, h23, l23;
-                split_pair(o[0], o[1], h01, l01);
-                split_pair(o[2], o[3], h23, l23);
+                if constexpr (Cfg::SPLIT) { split_pair(o[0], o[1], h01, l01); split_pair(o[2], o[3], h23, l23); }
+                else { h01 = round_pair(o[0], o[1]); h23 = round_pair(o[2], o[3]); l01 = h01; l23 = h23; }
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                 const h4 hv = {h01[0], h01[1], h23[0], h23[1]};
                 const h4 lv = {l01[0], l01[1], l23[0], l23[1]};
                 if (q < Cfg::NQ) {
                     const int off = q * (CIN * 2) + (((2 * m + (g >> 1)) ^ swz<CH>(q)) << 4) + (g & 1) * 8;
                     *reinterpret_cast<h4 *>(act + off) = hv;
-                    *reinterpret_cast<h4 *>(act + Cfg::PLANE_BYTES + off) = lv;
+                    if constexpr (Cfg::SPLIT) *reinterpret_cast<h4 *>(act + Cfg::PLANE_BYTES + off) = lv;
                 }
             }
         }
@@ -244,8 +251,8 @@ __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
         // two rows per pass and all index arithmetic is shifts and masks.  All global loads are issued before the
         // first LDS write, so a workgroup pays one HBM round trip.
         static_assert(HIN * CH == 128, "one image row of one plane = 128 chunks");
-        const _Float16 *in = static_cast<const _Float16 *>(a.in) + (size_t)patch * 2 * HIN * HIN * CIN;
-        constexpr int ROWS = 2 * IR, PASSES = (ROWS + 1) / 2;
+        const _Float16 *in = static_cast<const _Float16 *>(a.in) + (size_t)patch * Cfg::NPL * HIN * HIN * CIN;
+        constexpr int ROWS = Cfg::NPL * IR, PASSES = (ROWS + 1) / 2;
         const int rsub = tid >> 7, xc = tid & 127;              // row within the pass, chunk within the row
         const int x = xc / CH, c = xc % CH;
         h8 stage[PASSES];
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
         for (int m = 0; m < WM; ++m) {
             const char *p = wl + ((size_t)ks * MT + m) * 2048;
             dst[m].hi = *reinterpret_cast<const h8 *>(p);
-            dst[m].lo = *reinterpret_cast<const h8 *>(p + 1024);
+            if constexpr (Cfg::SPLIT) dst[m].lo = *reinterpret_cast<const h8 *>(p + 1024);
         }
     };
     auto load_b = [&](int ks, HL (&dst)[WN]) {          // ks is a compile-time constant after unrolling
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
             const int off = q * (CIN * 2) + (((kk * 4 + g) ^ swz<CH>(q)) << 4);
 #endif
             dst[t].hi = *reinterpret_cast<const h8 *>(act + off);
-            dst[t].lo = *reinterpret_cast<const h8 *>(act + Cfg::PLANE_BYTES + off);
+            if constexpr (Cfg::SPLIT) dst[t].lo = *reinterpret_cast<const h8 *>(act + Cfg::PLANE_BYTES + off);
         }
     };
     // weights (global, L2 latency) run two K-steps ahead, LDS fragments one
@@ -331,14 +338,16 @@ __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
         if (ks + 2 < Cfg::KS) load_a(ks + 2, abuf[(ks + 2) % 3]);
         if (ks + 1 < Cfg::KS) load_b(ks + 1, bbuf[nxt]);
         __builtin_amdgcn_sched_barrier(0);          // keep the prefetch distances exact
+        if constexpr (Cfg::SPLIT) {
 #pragma unroll
-        for (int m = 0; m < WM; ++m)
+            for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[ac][m].lo, bbuf[cur][t].hi, acc[m][t]);
+                for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[ac][m].lo, bbuf[cur][t].hi, acc[m][t]);
 #pragma unroll
-        for (int m = 0; m < WM; ++m)
+            for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[ac][m].hi, bbuf[cur][t].lo, acc[m][t]);
+                for (int t = 0; t < WN; ++t) acc[m][t] = mfma16(abuf[ac][m].hi, bbuf[cur][t].lo, acc[m][t]);
+        }
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
 
     HSTAMP(3);          // K loop
     // ---- bias (folded BatchNorm) + ReLU, split, store both planes ----
-    _Float16 *out = static_cast<_Float16 *>(a.out) + (size_t)patch * 2 * HOUT * HOUT * COUT;
+    _Float16 *out = static_cast<_Float16 *>(a.out) + (size_t)patch * Cfg::NPL * HOUT * HOUT * COUT;
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         const int co = 16 * (mg * WM + m) + 4 * g;
@@ -361,14 +370,14 @@ __global__ __launch_bounds__(256, Cfg::OCC) void hn_conv_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[m][t][r] + bb[r], 0.0f);
             h2 h01, l01, h23, l23;
-            split_pair(o[0], o[1], h01, l01);
-            split_pair(o[2], o[3], h23, l23);
+            if constexpr (Cfg::SPLIT) { split_pair(o[0], o[1], h01, l01); split_pair(o[2], o[3], h23, l23); }
+            else { h01 = round_pair(o[0], o[1]); h23 = round_pair(o[2], o[3]); l01 = h01; l23 = h23; }
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             const h4 hv = {h01[0], h01[1], h23[0], h23[1]};
             const h4 lv = {l01[0], l01[1], l23[0], l23[1]};
             const size_t e = ((size_t)oy * HOUT + ox) * COUT + co;
             *reinterpret_cast<h4 *>(out + e) = hv;
-            *reinterpret_cast<h4 *>(out + (size_t)HOUT * HOUT * COUT + e) = lv;
+            if constexpr (Cfg::SPLIT) *reinterpret_cast<h4 *>(out + (size_t)HOUT * HOUT * COUT + e) = lv;
         }
     }
     HSTAMP(4);          // epilogue
@@ -390,7 +399,9 @@ struct FcArgs {
 
 constexpr int kFcStageKs = 2, kFcStageBytes = kFcStageKs * 8 * 2048, kFcLds = 2 * kFcStageBytes;
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
+    constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int MT = 8, WN = 2, KS = kFcK / 32, NST = KS / kFcStageKs;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
         used[t] = p < a.n_patches && hn_patch_used(a.count, a.group, p);
         any |= used[t];
         p = p < a.n_patches ? p : a.n_patches - 1;
-        bp[t] = a.in + (size_t)p * 2 * kFcK + g * 8;
+        bp[t] = a.in + (size_t)p * NPL * kFcK + g * 8;
     }
     if (a.count != nullptr && !__syncthreads_or(any)) {      // a tile of masked slots: zero descriptors, no GEMM
 #pragma unroll
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
 #pragma unroll
             for (int t = 0; t < WN; ++t) {
                 breg[k2][t].hi = *reinterpret_cast<const h8 *>(bp[t] + (st * kFcStageKs + k2) * 32);
-                breg[k2][t].lo = *reinterpret_cast<const h8 *>(bp[t] + kFcK + (st * kFcStageKs + k2) * 32);
+                if constexpr (SPLIT) breg[k2][t].lo = *reinterpret_cast<const h8 *>(bp[t] + kFcK + (st * kFcStageKs + k2) * 32);
             }
     };
     fetch_w(0);
@@ -470,7 +481,10 @@ __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
                 wa.hi = *reinterpret_cast<const h8 *>(p);
                 wa.lo = *reinterpret_cast<const h8 *>(p + 1024);
 #pragma unroll
-                for (int t = 0; t < WN; ++t) acc[m][t] = mfma16x3(wa, bcur[k2][t], acc[m][t]);
+                for (int t = 0; t < WN; ++t) {
+                    if constexpr (SPLIT) acc[m][t] = mfma16x3(wa, bcur[k2][t], acc[m][t]);
+                    else acc[m][t] = mfma16(wa.hi, bcur[k2][t].hi, acc[m][t]);
+                }
             }
         put_w(buf ^ 1);
         __syncthreads();
@@ -503,11 +517,11 @@ __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
     }
 }
 
-using CfgL2 = ConvCfg<32, 32, 32, 1, 8, true>;
-using CfgL3 = ConvCfg<32, 64, 32, 2, 8, false>;
-using CfgL4 = ConvCfg<64, 64, 16, 1, 8, false>;
-using CfgL5 = ConvCfg<64, 128, 16, 2, 8, false>;
-using CfgL6 = ConvCfg<128, 128, 8, 1, 8, false>;
+template <bool SP> using CfgL2 = ConvCfg<32, 32, 32, 1, 8, true, SP>;
+template <bool SP> using CfgL3 = ConvCfg<32, 64, 32, 2, 8, false, SP>;
+template <bool SP> using CfgL4 = ConvCfg<64, 64, 16, 1, 8, false, SP>;
+template <bool SP> using CfgL5 = ConvCfg<64, 128, 16, 2, 8, false, SP>;
+template <bool SP> using CfgL6 = ConvCfg<128, 128, 8, 1, 8, false, SP>;
 
 constexpr size_t kBufA = (size_t)2 * 32 * 32 * 32 * 2;      // a2 (largest tenant): 128 KiB per patch
 constexpr size_t kBufB = (size_t)2 * 16 * 16 * 64 * 2;      // a3: 64 KiB per patch
@@ -611,18 +625,16 @@ extern "C" size_t balf_hardnet_workspace_bytes(int n_patches) {
     return c * (kBufA + kBufB) + (size_t)n_patches * kBufA6;
 }
 
-extern "C" int balf_hardnet_forward_masked(const void *packed_dev, const float *patches_dev, int n_patches, int group,
-                                           const int32_t *count_dev, float *desc_dev, void *workspace_dev,
-                                           size_t workspace_bytes, void *stream) {
-    if (!packed_dev || !patches_dev || !desc_dev || !workspace_dev || n_patches <= 0) return BALF_ERR_ARG;
-    if (count_dev && (group <= 0 || n_patches % group != 0)) return BALF_ERR_ARG;
-    if (workspace_bytes < balf_hardnet_workspace_bytes(n_patches)) return BALF_ERR_WORKSPACE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
+namespace {
+template <bool SP>
+int hardnet_forward_impl(const void *packed_dev, const float *patches_dev, int n_patches, int group, const int32_t *count_dev,
+                         float *desc_dev, void *workspace_dev, hipStream_t st) {
     const char *blob = static_cast<const char *>(packed_dev);
     const int chunk = n_patches < hn_chunk() ? n_patches : hn_chunk();
     char *bufA = static_cast<char *>(workspace_dev);
     char *bufB = bufA + (size_t)chunk * kBufA;
     char *a6 = bufB + (size_t)chunk * kBufB;
+    constexpr size_t a6_bytes = SP ? kBufA6 : kBufA6 / 2;              // one plane in plain-f16 mode
     auto bias = [&](int l) { return reinterpret_cast<const float *>(blob + hn_boff(l)); };
     for (int c0 = 0; c0 < n_patches; c0 += chunk) {
         const int n = n_patches - c0 < chunk ? n_patches - c0 : chunk;
@@ -632,22 +644,43 @@ extern "C" int balf_hardnet_forward_masked(const void *packed_dev, const float *
         a.count = count_dev; a.group = group > 0 ? group : 1; a.p0 = c0;
         a.in = patches_dev + (size_t)c0 * kPS * kPS; a.out = bufA;
         a.w = blob + hn_woff(1); a.bias = bias(1); a.w1 = blob + hn_woff(0); a.bias1 = bias(0);
-        if ((rc = launch_conv<CfgL2>(balf_prof::kHnConv2, a, st)) != BALF_OK) return rc;
+        if ((rc = launch_conv<CfgL2<SP>>(balf_prof::kHnConv2, a, st)) != BALF_OK) return rc;
         a.in = bufA; a.out = bufB; a.w = blob + hn_woff(2); a.bias = bias(2);
-        if ((rc = launch_conv<CfgL3>(balf_prof::kHnConv3, a, st)) != BALF_OK) return rc;
+        if ((rc = launch_conv<CfgL3<SP>>(balf_prof::kHnConv3, a, st)) != BALF_OK) return rc;
         a.in = bufB; a.out = bufA; a.w = blob + hn_woff(3); a.bias = bias(3);
-        if ((rc = launch_conv<CfgL4>(balf_prof::kHnConv4, a, st)) != BALF_OK) return rc;
+        if ((rc = launch_conv<CfgL4<SP>>(balf_prof::kHnConv4, a, st)) != BALF_OK) return rc;
         a.in = bufA; a.out = bufB; a.w = blob + hn_woff(4); a.bias = bias(4);
-        if ((rc = launch_conv<CfgL5>(balf_prof::kHnConv5, a, st)) != BALF_OK) return rc;
-        a.in = bufB; a.out = a6 + (size_t)c0 * kBufA6; a.w = blob + hn_woff(5); a.bias = bias(5);
-        if ((rc = launch_conv<CfgL6>(balf_prof::kHnConv6, a, st)) != BALF_OK) return rc;
+        if ((rc = launch_conv<CfgL5<SP>>(balf_prof::kHnConv5, a, st)) != BALF_OK) return rc;
+        a.in = bufB; a.out = a6 + (size_t)c0 * a6_bytes; a.w = blob + hn_woff(5); a.bias = bias(5);
+        if ((rc = launch_conv<CfgL6<SP>>(balf_prof::kHnConv6, a, st)) != BALF_OK) return rc;
     }
     // the final GEMM runs once over the whole batch (a chunk alone would fill 32 of the 256 CUs)
     FcArgs f{reinterpret_cast<const _Float16 *>(a6), desc_dev, blob + hn_woff(6), bias(6), n_patches, count_dev,
              group > 0 ? group : 1};
-    BALF_PROF(balf_prof::kHnFc, st, (hn_fc_kernel<<<balf_ceil_div(n_patches, 128), 256, kFcLds, st>>>(f)));
+    BALF_PROF(balf_prof::kHnFc, st, (hn_fc_kernel<SP><<<balf_ceil_div(n_patches, 128), 256, kFcLds, st>>>(f)));
     BALF_LAUNCH_CHECK();
     return BALF_OK;
+}
+}  // namespace
+
+extern "C" int balf_hardnet_forward_ex(const void *packed_dev, const float *patches_dev, int n_patches, int group,
+                                       const int32_t *count_dev, int precision, float *desc_dev, void *workspace_dev,
+                                       size_t workspace_bytes, void *stream) {
+    if (!packed_dev || !patches_dev || !desc_dev || !workspace_dev || n_patches <= 0) return BALF_ERR_ARG;
+    if (count_dev && (group <= 0 || n_patches % group != 0)) return BALF_ERR_ARG;
+    if (precision != BALF_HARDNET_SPLIT_F16 && precision != BALF_HARDNET_PLAIN_F16) return BALF_ERR_ARG;
+    if (workspace_bytes < balf_hardnet_workspace_bytes(n_patches)) return BALF_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return precision == BALF_HARDNET_SPLIT_F16
+               ? hardnet_forward_impl<true>(packed_dev, patches_dev, n_patches, group, count_dev, desc_dev, workspace_dev, st)
+               : hardnet_forward_impl<false>(packed_dev, patches_dev, n_patches, group, count_dev, desc_dev, workspace_dev, st);
+}
+
+extern "C" int balf_hardnet_forward_masked(const void *packed_dev, const float *patches_dev, int n_patches, int group,
+                                           const int32_t *count_dev, float *desc_dev, void *workspace_dev,
+                                           size_t workspace_bytes, void *stream) {
+    return balf_hardnet_forward_ex(packed_dev, patches_dev, n_patches, group, count_dev, BALF_HARDNET_SPLIT_F16, desc_dev,
+                                   workspace_dev, workspace_bytes, stream);
 }
 
 extern "C" int balf_hardnet_forward(const void *packed_dev, const float *patches_dev, int n_patches, float *desc_dev,

@@ -142,6 +142,15 @@ int balf_hardnet_forward(const void *packed_dev, const float *patches_dev, int n
 int balf_hardnet_forward_masked(const void *packed_dev, const float *patches_dev, int n_patches, int group,
                                 const int32_t *count_dev, float *desc_dev, void *workspace_dev, size_t workspace_bytes,
                                 void *stream);
+/* Same with a choice of operand precision: BALF_HARDNET_SPLIT_F16 (default everywhere else: hi+lo operands, three
+ * products, descriptors within ~1e-6 of fp32) or BALF_HARDNET_PLAIN_F16 (one f16 product, activations stored as one
+ * plane: about twice as fast, descriptors within ~5e-4 -- the accuracy class of the TF32 convolutions PyTorch uses
+ * by default for this network on an NVIDIA GPU). */
+#define BALF_HARDNET_SPLIT_F16 0
+#define BALF_HARDNET_PLAIN_F16 1
+int balf_hardnet_forward_ex(const void *packed_dev, const float *patches_dev, int n_patches, int group,
+                            const int32_t *count_dev, int precision, float *desc_dev, void *workspace_dev,
+                            size_t workspace_bytes, void *stream);
 
 /* ---- patch extraction and descriptor matching of the demo path -------------------------
  * balf_extract_patches replaces kornia.feature.laf_from_center_scale_ori + extract_patches_from_pyramid(PS=32) as

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the demo's feature half for a batch: uint8 images -> detector -> greedy NMS + sub-pixel -> 32x32
 patches -> HardNet descriptors (demo_match.extract_features per image), plus one mutual-NN match of two images.
-Usage: python tools/bench_demo.py [batch] [H] [W] [steps]"""
+Usage: python tools/bench_demo.py [batch] [H] [W] [steps] [fp16-split|fp16 (descriptor operands)]"""
 import json
 import os
 import sys
@@ -23,6 +23,7 @@ def main():
     h = int(sys.argv[2]) if len(sys.argv) > 2 else 1080
     w = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+    desc_precision = sys.argv[5] if len(sys.argv) > 5 else "fp16-split"
     dev = torch.device("cuda:0")
     det = get_model.load_model(arch.DEFAULT_MODEL_CFG)
     det.load_state_dict(synth.synthetic_state_dict(20240))
@@ -30,6 +31,7 @@ def main():
     det = det.eval().to(dev)
     hn = HardNet()
     hn.load_state_dict(synth.synthetic_hardnet_state_dict(515))
+    hn.precision = desc_precision
     hn = hn.eval().to(dev)
     imgs = torch.from_numpy(np.stack([synth.synthetic_gray_u8(h, w, i, blur=5 if i % 2 == 0 else 3) for i in range(b)])).to(dev)
     args = demo_match.DEFAULT_ARGS
@@ -75,7 +77,7 @@ def main():
                       "descriptors_per_s": b * kp / dt, "device_ms": groups,
                       "match_smnn_ms": t_match * 1e3, "match_pairs": [n0, n1], "matches": int(ids.shape[0]),
                       "match_smnn_batch_ms": (t_batch * 1e3 if half else None), "match_batch_pairs": half,
-                      "dtype": "split-f16 MFMA detector and descriptor, fp32 everything else"}))
+                      "dtype": f"split-f16 MFMA detector, descriptor {desc_precision}, fp32 everything else"}))
 
 
 if __name__ == "__main__":

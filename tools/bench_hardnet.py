@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the HardNet descriptor kernels (per-kernel device ms through balf_profile_*) and report accuracy.
-Usage: python tools/bench_hardnet.py [n_patches] [reps]"""
+Usage: python tools/bench_hardnet.py [n_patches] [reps] [fp16-split|fp16]"""
 import ctypes as C
 import os
 import sys
@@ -22,6 +22,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     m = HardNet()
+    m.precision = sys.argv[3] if len(sys.argv) > 3 else "fp16-split"
     m.load_state_dict(synth.synthetic_hardnet_state_dict(515))
     m = m.eval().to("cuda:0")
     base = synth.synthetic_patches(2048, 3).to("cuda:0")
@@ -68,11 +69,14 @@ def main():
     ach = 2 * mac * n / (ms[dom] * 1e-3) / 1e12
     print(json.dumps({
         "metric": "HardNet descriptors/s (demo path, 32x32 patches -> 128-d)", "value": n / dt, "unit": "patches/s",
-        "n_patches": n, "ms": dt * 1e3, "dtype": "f16 MFMA, split hi+lo operands (3 products), f32 accumulate",
+        "n_patches": n, "ms": dt * 1e3,
+        "dtype": ("f16 MFMA, split hi+lo operands (3 products), f32 accumulate" if m.precision == "fp16-split"
+                  else "f16 MFMA, plain f16 operands, f32 accumulate"),
         "max_abs_err_vs_fp64": err,
         "roofline": {"kernel": l.balf_profile_slot_name(dom).decode(), "bound": "mfma", "achieved": ach,
-                     "peak": 2500.0 / 3, "unit": "TFLOP/s", "frac": ach / (2500.0 / 3),
-                     "note": "algorithmic FLOP (one product per MAC) against the f16 dense peak / 3 split products"},
+                     "peak": 2500.0 / (3 if m.precision == "fp16-split" else 1), "unit": "TFLOP/s",
+                     "frac": ach / (2500.0 / (3 if m.precision == "fp16-split" else 1)),
+                     "note": "algorithmic FLOP (one product per MAC) against the f16 dense peak / products per MAC"},
         "cpu_baseline": {"value": 1000 / cpu_dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
                          "sample": f"1000 patches, oracle.hardnet_forward (torch CPU fp32), {cpu_dt:.2f} s"}}))
 
