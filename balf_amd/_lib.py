@@ -49,6 +49,7 @@ PROTOTYPES = {
     "balf_extract_patches": (_i, [_vp, _i, _i, _fp, _i, C.c_float, _fp, _vp, _sz, _vp]),
     "balf_extract_patches_batch_workspace_bytes": (_sz, [_i, _i, _i, C.c_float]),
     "balf_extract_patches_batch": (_i, [_vp, _i, _i, _i, _fp, _vp, _i, C.c_float, _fp, _vp, _sz, _vp]),
+    "balf_rgb_to_gray": (_i, [_vp, C.c_long, _vp, _vp]),
     "balf_match_smnn_workspace_bytes": (_sz, [_i, _i]),
     "balf_match_smnn": (_i, [_fp, _i, _fp, _i, C.c_float, _vp, _fp, _vp, _vp, _sz, _vp]),
     "balf_match_smnn_batch_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -102,6 +102,14 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     }
 }
 
+// PIL's Image.convert('L') (ITU-R 601-2 luma, fixed point): what demo_match.load_im produces (demo_match.py:13-19)
+__global__ void rgb_to_gray_kernel(const unsigned char *rgb, unsigned char *gray, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+        gray[i] = (unsigned char)((r * 19595u + g * 38470u + b * 7471u + 0x8000u) >> 16);
+    }
+}
+
 int pyramid_level(int h, int w, float scale) {
     const float s = sqrtf(scale * scale + 1e-10f);
     const int max_level = (h < w ? h : w) / kPS;
@@ -174,4 +182,13 @@ extern "C" int balf_extract_patches(const unsigned char *gray_dev, int H, int W,
                                     void *stream) {
     return balf_extract_patches_batch(gray_dev, 1, H, W, xy_dev, nullptr, n_points, scale, patches_dev, workspace_dev,
                                       workspace_bytes, stream);
+}
+
+extern "C" int balf_rgb_to_gray(const unsigned char *rgb_dev, long n_pixels, unsigned char *gray_dev, void *stream) {
+    if (!rgb_dev || !gray_dev || n_pixels <= 0) return BALF_ERR_ARG;
+    const long blocks = (n_pixels + 255) / 256;
+    rgb_to_gray_kernel<<<(unsigned)(blocks < 65536 ? blocks : 65536), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        rgb_dev, gray_dev, n_pixels);
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
 }

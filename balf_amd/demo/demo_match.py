@@ -53,10 +53,8 @@ def detect_and_describe_batch(args, images_u8: torch.Tensor, detector, descripto
     is what :func:`extract_features` returns (demo_match.py:59-95)."""
     if args.order_coord != "xysr":
         raise NotImplementedError("the demo path is implemented for order_coord='xysr' (the reference default)")
-    if gray_u8 is None:
-        if images_u8.dim() != 3:
-            raise ValueError("RGB input needs the gray images (PIL's convert('L'), demo_match.py:15-17) in gray_u8")
-        gray_u8 = images_u8
+    if gray_u8 is None:       # RGB without its gray version: PIL's convert('L') arithmetic on the GPU (demo_match.py:15-17)
+        gray_u8 = images_u8 if images_u8.dim() == 3 else ops.rgb_to_gray_u8(images_u8.contiguous())
     b, h, w = images_u8.shape[:3]
     _, _, top, left = arch.padded_hw(h, w)
     k = min(int(args.num_features), h * w)

@@ -130,6 +130,20 @@ def extract_patches(gray_u8: torch.Tensor, xy: torch.Tensor, scale: float) -> to
     return out
 
 
+def rgb_to_gray_u8(rgb_u8: torch.Tensor) -> torch.Tensor:
+    """uint8 RGB [...,3] on the GPU -> uint8 gray [...] with PIL's ``convert('L')`` arithmetic, which is what the
+    demo's ``load_im`` feeds the patch extractor (/root/reference/demo/demo_match.py:13-19)."""
+    require_gpu_tensor(rgb_u8, "rgb_u8")
+    if rgb_u8.dtype != torch.uint8 or rgb_u8.shape[-1] != 3:
+        raise BalfHipError("rgb_u8 must be a uint8 tensor with a last dimension of 3")
+    out = torch.empty(rgb_u8.shape[:-1], dtype=torch.uint8, device=rgb_u8.device)
+    if out.numel():
+        with torch.cuda.device(rgb_u8.device):
+            check(lib().balf_rgb_to_gray(rgb_u8.data_ptr(), out.numel(), out.data_ptr(), current_stream_ptr(rgb_u8.device)),
+                  "balf_rgb_to_gray")
+    return out
+
+
 def extract_patches_batch(gray_u8: torch.Tensor, xy: torch.Tensor, count, scale: float) -> torch.Tensor:
     """Batched :func:`extract_patches`: gray_u8 [B,H,W] uint8, xy [B,K,2], count [B] int32 (or None: all K valid) ->
     patches [B,K,1,32,32]; slots past an image's count are zero patches (balf_extract_patches_batch)."""

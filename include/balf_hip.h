@@ -170,6 +170,8 @@ size_t balf_extract_patches_batch_workspace_bytes(int B, int H, int W, float sca
 int balf_extract_patches_batch(const unsigned char *gray_dev, int B, int H, int W, const float *xy_dev,
                                const int32_t *count_dev, int K, float scale, float *patches_dev, void *workspace_dev,
                                size_t workspace_bytes, void *stream);
+/* uint8 RGB (interleaved, n_pixels x 3) -> uint8 gray exactly as PIL's Image.convert('L') (demo_match.py:13-19). */
+int balf_rgb_to_gray(const unsigned char *rgb_dev, long n_pixels, unsigned char *gray_dev, void *stream);
 size_t balf_match_smnn_workspace_bytes(int n1, int n2);
 /* Batched form: `pairs` independent problems, desc1_dev [pairs,k1,128] / desc2_dev [pairs,k2,128] with n1_dev / n2_dev
  * [pairs] valid rows each; idx_dev [pairs,min(k1,k2),2], dist_dev [pairs,min(k1,k2)], count_dev [pairs]. */

@@ -192,3 +192,23 @@ def test_match_smnn_batch_equals_per_pair():
         assert c == gi.shape[0]
         assert torch.equal(idx[i, :c].long(), gi) and torch.equal(dist[i, :c], gd.view(-1))
         assert bool((idx[i, c:] == -1).all())
+
+
+def test_rgb_to_gray_matches_pil():
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, size=(2, 67, 91, 3), dtype=np.uint8)
+    rgb[0, 0, :8] = [[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [1, 1, 1], [254, 255, 255], [128, 127, 129]]
+    ref = np.stack([np.array(Image.fromarray(im).convert("L")) for im in rgb])
+    got = ops.rgb_to_gray_u8(torch.from_numpy(rgb).to(DEV)).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
+def test_batched_rgb_input(models):
+    det, hn = models
+    rng = np.random.default_rng(4)
+    rgb = torch.from_numpy(rng.integers(0, 256, size=(2, 120, 160, 3), dtype=np.uint8)).to(DEV)
+    xy, desc, count = demo_match.detect_and_describe_batch(demo_match.DEFAULT_ARGS, rgb, det, hn)
+    gray = ops.rgb_to_gray_u8(rgb)
+    xy2, desc2, count2 = demo_match.detect_and_describe_batch(demo_match.DEFAULT_ARGS, rgb, det, hn, gray_u8=gray)
+    assert torch.equal(xy, xy2) and torch.equal(desc, desc2) and torch.equal(count, count2)
