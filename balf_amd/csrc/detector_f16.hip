@@ -798,6 +798,402 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// N-split variant of the branch kernels for C = 256 (BALF_NS256).  The register state of 16 pixels x 256 channels
+// x several live tensors pins the kernels above to ONE wave per SIMD at C = 256.  Here a workgroup is 8 waves: each
+// 16-pixel tile is shared by a PAIR of waves and each wave of the pair holds half of the output channels of every
+// Linear (8 of the 16 row tiles), so a wave needs half the registers and two waves fit on a SIMD.  The two halves
+// meet in LDS: the B operand slot of a pixel tile is written half by each wave (a wave's 8 tiles are 4 complete
+// K-steps of the next Linear), LayerNorm statistics are exchanged through a small LDS array, and a weight-ring unit
+// carries the 4 row tiles of both halves (16 KiB).  Everything else -- token mix, gating, residuals, SE sums,
+// stores -- is local to a wave's channels.
+// ------------------------------------------------------------------------------------------------
+#ifndef BALF_NS256
+#define BALF_NS256 1
+#endif
+constexpr int kNsRingSlots = 4;
+constexpr int kNsRingSlotBytes = 8 * 2048;
+constexpr int kNsRingBytes = kNsRingSlots * kNsRingSlotBytes;
+
+struct RingGemmNs {
+    const char *wbase;
+    int wnt0, KStot, ks0, ksn;
+    int chunks;            // groups of 4 row tiles PER HALF (units = chunks * ksn)
+    int half_tiles;        // row-tile distance between the two halves (0: both halves get the same tiles)
+};
+struct RingChainNs {
+    RingGemmNs g[4];
+    int tot[4];
+};
+
+__device__ __forceinline__ RingChainNs make_chain_ns(const RingGemmNs &g0, const RingGemmNs &g1, const RingGemmNs &g2,
+                                                     const RingGemmNs &g3, int n) {
+    RingChainNs c;
+    c.g[0] = g0; c.g[1] = g1; c.g[2] = g2; c.g[3] = g3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.tot[i] = (i < n) ? c.g[i].chunks * c.g[i].ksn : 0;
+    return c;
+}
+
+// wave8 (0..7) fetches row tile (wave8 & 3) of half (wave8 >> 2) of chain-relative unit t
+__device__ __forceinline__ void chain_issue_ns(const RingChainNs &c, unsigned char *ring, int t, int slot, int wave8,
+                                               int lane) {
+    RingGemmNs d = c.g[0];
+    bool valid = c.tot[0] > 0, walking = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (walking) {
+            if (valid && t >= c.tot[i]) {
+                t -= c.tot[i];
+                if (i < 3) { d = c.g[i + 1]; valid = c.tot[i + 1] > 0; }
+                else valid = false;
+            } else {
+                walking = false;
+            }
+        }
+    if (!valid) return;
+    const int cc = t / d.ksn, k = t - cc * d.ksn;
+    const int tile = d.wnt0 + (wave8 >> 2) * d.half_tiles + cc * 4 + (wave8 & 3);
+    const char *src = d.wbase + ((size_t)tile * d.KStot + d.ks0 + k) * 2048 + lane * 16;
+    unsigned char *dst = ring + slot * kNsRingSlotBytes + wave8 * 2048;
+    __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void *)(src + 1024), (lds_void *)(dst + 1024), 16, 0, 0);
+}
+
+template <int NTL, int CI, int P, typename BL>
+__device__ __forceinline__ void chain_chunk_ns(f4 (&acc)[NTL][P], const RingChainNs &c, unsigned char *ring, int gu,
+                                               int lane, int wave8, int hh, BL bload) {
+    if constexpr (CI * 4 < NTL) {
+        const int ksn = c.g[0].ksn;
+        const int later = c.tot[1] + c.tot[2] + c.tot[3];
+        for (int k = 0; k < ksn; ++k) {
+            const int u = CI * ksn + k;
+            ring_wait_barrier(c.tot[0] - 1 - u + later);
+            chain_issue_ns(c, ring, u + kNsRingSlots - 1, (gu + u + kNsRingSlots - 1) & (kNsRingSlots - 1), wave8, lane);
+            HL a[4], b[P];
+            const unsigned char *sl = ring + ((gu + u) & (kNsRingSlots - 1)) * kNsRingSlotBytes + hh * 8192 + lane * 16;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                a[nt].hi = *reinterpret_cast<const h8 *>(sl + nt * 2048);
+                a[nt].lo = *reinterpret_cast<const h8 *>(sl + nt * 2048 + 1024);
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) b[p] = bload(k, p);
+            ring_mfma<NTL, CI, P>(acc, a, b);
+        }
+        chain_chunk_ns<NTL, CI + 1, P>(acc, c, ring, gu, lane, wave8, hh, bload);
+    }
+}
+
+template <int NTL, int P, typename BL>
+__device__ __forceinline__ void gemm16_chain_ns(f4 (&acc)[NTL][P], const RingChainNs &c, int &gu, int lane, int wave8,
+                                                int hh, unsigned char *ring, BL bload) {
+    chain_chunk_ns<NTL, 0, P>(acc, c, ring, gu, lane, wave8, hh, bload);
+    gu += c.tot[0];
+}
+
+// LayerNorm statistics over all C channels of a pixel: this wave's half + the partner's, through LDS
+// (lnx: [which 0/1][pair 4][half 2][16 pixels]); all 8 waves call this together (two barriers).
+template <int NTL>
+__device__ __forceinline__ void ln_stats_ns(const f4 (&x)[NTL][1], float *lnx, int pg, int hh, int q, int li, float &mean,
+                                            float &rstd) {
+    constexpr float inv_c = 1.0f / (32 * NTL);
+    float s = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) s += (x[nt][0][0] + x[nt][0][1]) + (x[nt][0][2] + x[nt][0][3]);
+    s = quarter_allreduce(s);
+    if (q == 0) lnx[(pg * 2 + hh) * 16 + li] = s;
+    lds_barrier();
+    mean = (lnx[(pg * 2) * 16 + li] + lnx[(pg * 2 + 1) * 16 + li]) * inv_c;
+    float v = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = x[nt][0][r] - mean;
+            v = fmaf(d, d, v);
+        }
+    v = quarter_allreduce(v);
+    if (q == 0) lnx[128 + (pg * 2 + hh) * 16 + li] = v;
+    lds_barrier();
+    rstd = __builtin_amdgcn_rsqf((lnx[128 + (pg * 2) * 16 + li] + lnx[128 + (pg * 2 + 1) * 16 + li]) * inv_c + kLnEps);
+}
+
+constexpr int ns_lds_bytes() {
+    constexpr int C = 256;
+    constexpr int slots = 4 * (C / 32) * 2048;                 // one B-operand slot per pixel tile (shared by a pair)
+    constexpr int bt = 2 * C * kBtPitch16 * 2;
+    return (slots > bt ? slots : bt) + 4 * C * 4 + kNsRingBytes + par_floats<C>() * 4 + 256 * 4;
+}
+
+template <int CIN, int MODE>
+__global__ __launch_bounds__(512, 1) void stage_branch_kernel16_ns(StageArgs A) {
+    constexpr int C = 256, P = 1, NT = 16, NTL = 8, KS = 8, KSL = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int slots_b = 4 * KS * 2048, bt_b = 2 * C * kBtPitch16 * 2;
+    constexpr int main_bytes = slots_b > bt_b ? slots_b : bt_b;
+    _Float16 *bT = reinterpret_cast<_Float16 *>(smem_raw);                 // [hi|lo][c][pitch]
+    float *red = reinterpret_cast<float *>(smem_raw + main_bytes);         // [4][C]
+    unsigned char *ring = smem_raw + main_bytes + 4 * C * 4;
+    float *par = reinterpret_cast<float *>(smem_raw + main_bytes + 4 * C * 4 + kNsRingBytes);
+    float *lnx = par + par_floats<C>();
+
+    const int lane = threadIdx.x & 63, wave8 = threadIdx.x >> 6, q = lane >> 4, li = lane & 15;
+    const int pg = wave8 >> 1, hh = wave8 & 1;         // pixel tile of the token group, channel half
+    const int nt0 = hh * NTL, ks0 = hh * KSL;
+    h8 *slot = reinterpret_cast<h8 *>(smem_raw) + pg * (KS * 2 * 64);     // [ks][hi|lo][lane], shared by the pair
+    const float *blob = A.blob;
+    const StageOff &S = A.off;
+    const BranchOff &Br = S.br[MODE];
+
+    const int H = A.H, W = A.W;
+    const int cols = W / 8;
+    const int per_img = (H / 8) * cols;
+    const int nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xl = blockIdx.x & 7, xj = blockIdx.x >> 3;
+    const int item = (xl < xr ? xl * (xq + 1) : xr * (xq + 1) + (xl - xr) * xq) + xj;
+    const int n = item / per_img;
+    const int rem = item - n * per_img;
+    const int iy0 = rem / cols, ix0 = rem - iy0 * cols;
+    const int tok = 16 * pg + li, ty = tok >> 3, tx = tok & 7;
+    int y, x;
+    if (MODE == 0) { y = ty * (H / 8) + iy0; x = tx * (W / 8) + ix0; }
+    else           { y = 8 * iy0 + ty;       x = 8 * ix0 + tx; }
+    const long pix = ((long)n * H + y) * W + x;
+
+    constexpr int NG = (MODE == 0) ? 6 : 10;
+    const char *bb = reinterpret_cast<const char *>(blob);
+    RingGemmNs seq[NG + 3];
+    {
+        constexpr int CH = NTL / 4, KI = CIN / 32, HT = NT / 2;
+        int i = 0;
+        seq[i++] = RingGemmNs{bb + (size_t)S.conv0_w * 4, 0, KI, 0, KI, CH, HT};
+        seq[i++] = RingGemmNs{bb + (size_t)S.q1_w * 4, MODE * NT, KS, 0, KS, CH, HT};
+        seq[i++] = RingGemmNs{bb + (size_t)Br.d1_w * 4, 0, KS, 0, KS, CH, HT};
+        seq[i++] = RingGemmNs{bb + (size_t)Br.d1_w * 4, NT, KS, 0, KS, CH, HT};
+        seq[i++] = RingGemmNs{bb + (size_t)Br.mix_w * 4, 0, 2, 0, 2, 1, 0};        // 64x64 token-mix matrix: 2 units
+        seq[i++] = RingGemmNs{bb + (size_t)Br.d2_w * 4, 0, KS, 0, KS, CH, HT};
+        if (MODE == 1) {
+            seq[i++] = RingGemmNs{bb + (size_t)S.q2_w * 4, 0, 2 * KS, KS, KS, CH, HT};
+            seq[i++] = RingGemmNs{bb + (size_t)S.q2_w * 4, 0, 2 * KS, 0, KS, CH, HT};
+            seq[i++] = RingGemmNs{bb + (size_t)S.r1_w * 4, 0, KS, 0, KS, CH, HT};
+            seq[i++] = RingGemmNs{bb + (size_t)S.r2_w * 4, 0, KS, 0, KS, CH, HT};
+        }
+    }
+    seq[NG] = seq[0]; seq[NG + 1] = seq[0]; seq[NG + 2] = seq[0];
+    int gu = 0;
+
+    // ---- prologue: stage input (this wave's half of the K-steps) -> shared slot, ring prime, parameter cache ----
+    {
+        constexpr int KIH = CIN / 32 / 2;
+        HL xin[KIH];
+#pragma unroll
+        for (int kk = 0; kk < KIH; ++kk) xin[kk] = load_frag_px(A.X, pix, CIN, hh * KIH + kk, q);
+#pragma unroll
+        for (int kk = 0; kk < KIH; ++kk) {
+            slot[((hh * KIH + kk) * 2 + 0) * 64 + lane] = xin[kk].hi;
+            slot[((hh * KIH + kk) * 2 + 1) * 64 + lane] = xin[kk].lo;
+        }
+    }
+    {
+        const RingChainNs c0 = make_chain_ns(seq[0], seq[1], seq[2], seq[3], NG);
+#pragma unroll
+        for (int t = 0; t < kNsRingSlots - 1; ++t) chain_issue_ns(c0, ring, t, t, wave8, lane);
+    }
+    {
+        auto put = [&](int dst, int src, int n_) {
+            for (int i = threadIdx.x; i < n_; i += 512) par[dst + i] = blob[src + i];
+        };
+        put(kParConv0B * C, S.conv0_b, C);
+        put(kParQ1B * C, S.q1_b + MODE * C, C);
+        put(kParD1B * C, Br.d1_b, 2 * C);
+        put(kParGlnG * C, Br.gln_g, C);
+        put(kParGlnB * C, Br.gln_b, C);
+        put(kParD2B * C, Br.d2_b, C);
+        put(kParMixB * C, Br.mix_b, 64);
+        if (MODE == 1) {
+            put(kParQ2B * C + 64, S.q2_b, C);
+            put(kParR1B * C + 64, S.r1_b, C);
+            put(kParR2B * C + 64, S.r2_b, C);
+        }
+        __syncthreads();
+    }
+
+    auto G = [&](auto idx, auto &acc, auto bload) {
+        constexpr int I = decltype(idx)::value;
+        const RingChainNs c = make_chain_ns(seq[I], seq[I + 1], seq[I + 2], seq[I + 3], NG - I);
+        gemm16_chain_ns<NTL, P>(acc, c, gu, lane, wave8, hh, ring, bload);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
+    using I8 = std::integral_constant<int, 8>; using I9 = std::integral_constant<int, 9>;
+    auto from_slot = [&](int kk, int) {
+        HL o;
+        o.hi = slot[(kk * 2 + 0) * 64 + lane];
+        o.lo = slot[(kk * 2 + 1) * 64 + lane];
+        return o;
+    };
+    // this wave's 8 tiles are K-steps ks0 .. ks0+3 of the next Linear; the barrier in front keeps the partner's (and
+    // this wave's) reads of the previous contents ahead of the overwrite, the ring's first barrier publishes it
+    auto to_slot = [&](const f4 (&t)[NTL][P]) {
+        lds_barrier();
+        store_slot16(slot + ks0 * (2 * 64), t, lane);
+    };
+    auto ln_plain = [&](const f4 (&xin_)[NTL][P], f4 (&yout)[NTL][P]) {
+        float mean, rstd;
+        ln_stats_ns<NTL>(xin_, lnx, pg, hh, q, li, mean, rstd);
+        const float shift = -mean * rstd;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yout[nt][0][r] = fmaf(xin_[nt][0][r], rstd, shift);
+    };
+
+    // ---- x0 = relu(conv0(X)) ----
+    f4 x0[NTL][P];
+    init_bias(x0, par + kParConv0B * C + 16 * nt0, q);
+    G(I0{}, x0, from_slot);
+    relu(x0);
+    {
+        f4 h[NTL][P];
+        ln_plain(x0, h);
+        to_slot(h);
+    }
+    f4 z[NTL][P];
+    init_bias(z, par + kParQ1B * C + 16 * nt0, q);
+    G(I1{}, z, from_slot);
+    gelu<false>(z);
+    {
+        f4 h[NTL][P];
+        ln_plain(z, h);
+        to_slot(h);
+    }
+    f4 ga[NTL][P];
+    init_bias(ga, par + kParD1B * C + 16 * nt0, q);
+    G(I2{}, ga, from_slot);
+    gelu<false>(ga);
+    {
+        f4 gb[NTL][P];
+        init_bias(gb, par + kParD1B * C + C + 16 * nt0, q);
+        G(I3{}, gb, from_slot);
+        gelu<false>(gb);
+        {
+            float mean, rstd;
+            ln_stats_ns<NTL>(gb, lnx, pg, hh, q, li, mean, rstd);
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                const f4 gg = ldg4(par + kParGlnG * C + 16 * (nt0 + nt) + 4 * q), be = ldg4(par + kParGlnB * C + 16 * (nt0 + nt) + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gb[nt][0][r] = (gb[nt][0][r] - mean) * rstd * gg[r] + be[r];
+            }
+        }
+        lds_barrier();                                  // slots (aliased by bT) are no longer read
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+            h2 h01, l01, h23, l23;
+            split_pair(gb[nt][0][0], gb[nt][0][1], h01, l01);
+            split_pair(gb[nt][0][2], gb[nt][0][3], h23, l23);
+            _Float16 *row = bT + (16 * (nt0 + nt) + 4 * q) * kBtPitch16 + tok;
+            _Float16 *rowl = row + C * kBtPitch16;
+            row[0] = h01[0]; row[kBtPitch16] = h01[1]; row[2 * kBtPitch16] = h23[0]; row[3 * kBtPitch16] = h23[1];
+            rowl[0] = l01[0]; rowl[kBtPitch16] = l01[1]; rowl[2 * kBtPitch16] = l23[0]; rowl[3 * kBtPitch16] = l23[1];
+        }
+    }
+    lds_barrier();
+    {
+        // the mixing matrix arrives through the ring as chain entry 4 (two units); this wave needs row tile pg of each
+        HL w0, w1;
+        const RingChainNs c = make_chain_ns(seq[4], seq[5], seq[6], seq[7], NG - 4);
+        const int later = c.tot[1] + c.tot[2] + c.tot[3];
+        auto rd = [&](HL &w, int g) {
+            const unsigned char *sl = ring + (g & (kNsRingSlots - 1)) * kNsRingSlotBytes + pg * 2048 + lane * 16;
+            w.hi = *reinterpret_cast<const h8 *>(sl);
+            w.lo = *reinterpret_cast<const h8 *>(sl + 1024);
+        };
+        ring_wait_barrier(1 + later);
+        chain_issue_ns(c, ring, kNsRingSlots - 1, (gu + kNsRingSlots - 1) & (kNsRingSlots - 1), wave8, lane);
+        rd(w0, gu);
+        ring_wait_barrier(later);
+        chain_issue_ns(c, ring, kNsRingSlots, (gu + kNsRingSlots) & (kNsRingSlots - 1), wave8, lane);
+        rd(w1, gu + 1);
+        gu += 2;
+        const float mb1 = par[kParMixB * C + tok] + 1.0f;
+#pragma unroll
+        for (int ct = 0; ct < NTL; ++ct) {
+            const _Float16 *row = bT + (16 * (nt0 + ct) + li) * kBtPitch16 + 8 * q;
+            const _Float16 *rowl = row + C * kBtPitch16;
+            HL a0, a1;
+            a0.hi = *reinterpret_cast<const h8 *>(row);      a0.lo = *reinterpret_cast<const h8 *>(rowl);
+            a1.hi = *reinterpret_cast<const h8 *>(row + 32); a1.lo = *reinterpret_cast<const h8 *>(rowl + 32);
+            f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
+            m = mfma16x3(a0, w0, m);
+            m = mfma16x3(a1, w1, m);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ga[ct][0][r] *= (m[r] + mb1);
+        }
+    }
+    to_slot(ga);                                        // (its barrier also ends the reads of bT)
+    f4 o[NTL][P];
+    init_bias(o, par + kParD2B * C + 16 * nt0, q);
+    G(I5{}, o, from_slot);
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) o[nt][0] += z[nt][0];
+
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int ks = 0; ks < KSL; ++ks) store_frag_px(A.U, pix, C, ks0 + ks, q, split8(o[2 * ks][0], o[2 * ks + 1][0]));
+        return;
+    } else {
+        HL ub[KSL];                                     // this wave's half of the u' K-steps, in flight during G(I6)
+#pragma unroll
+        for (int kk = 0; kk < KSL; ++kk) ub[kk] = load_frag_px(A.U, pix, C, ks0 + kk, q);
+        to_slot(o);
+        f4 x1[NTL][P];
+        init_bias(x1, par + kParQ2B * C + 64 + 16 * nt0, q);
+        G(I6{}, x1, from_slot);
+        lds_barrier();
+#pragma unroll
+        for (int kk = 0; kk < KSL; ++kk) {
+            slot[((ks0 + kk) * 2 + 0) * 64 + lane] = ub[kk].hi;
+            slot[((ks0 + kk) * 2 + 1) * 64 + lane] = ub[kk].lo;
+        }
+        G(I7{}, x1, from_slot);
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+            x1[nt][0] += x0[nt][0];
+            *reinterpret_cast<f4 *>(A.R + pix * C + 16 * (nt0 + nt) + 4 * q) = x1[nt][0] + x0[nt][0];
+        }
+        ln_plain(x1, x1);
+        to_slot(x1);
+        f4 m1[NTL][P];
+        init_bias(m1, par + kParR1B * C + 64 + 16 * nt0, q);
+        G(I8{}, m1, from_slot);
+        lrelu(m1);
+        to_slot(m1);
+        f4 t[NTL][P];
+        init_bias(t, par + kParR2B * C + 64 + 16 * nt0, q);
+        G(I9{}, t, from_slot);
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+            *reinterpret_cast<f4 *>(A.T + pix * C + 16 * (nt0 + nt) + 4 * q) = t[nt][0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = t[nt][0][r];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                if (li == 0) red[pg * C + 16 * (nt0 + nt) + 4 * q + r] = v;
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 512)
+            A.partial[(long)item * C + c] = (red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c]);
+    }
+}
+
 // x2 = t*s + r, 2x2 max pool, written in fragment format for the next stage's MFMA B operand.
 template <int C>
 __global__ __launch_bounds__(256) void pool_kernel16(const float *__restrict__ T, const float *__restrict__ R,
@@ -918,8 +1314,22 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
                 hipSuccess)
             return BALF_ERR_LAUNCH;
     }
-    BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(k0, dim3(nwg), dim3(256), lds, st, a));
-    BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(k1, dim3(nwg), dim3(256), lds, st, a));
+    if constexpr (C == 256 && BALF_NS256 != 0) {
+        constexpr int nlds = ns_lds_bytes();
+        static_assert(nlds <= 160 * 1024, "N-split LDS image");
+        auto n0 = stage_branch_kernel16_ns<CIN, 0>;
+        auto n1 = stage_branch_kernel16_ns<CIN, 1>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(n0), hipFuncAttributeMaxDynamicSharedMemorySize, nlds) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(n1), hipFuncAttributeMaxDynamicSharedMemorySize, nlds) !=
+                hipSuccess)
+            return BALF_ERR_LAUNCH;
+        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(n0, dim3(nwg), dim3(512), nlds, st, a));
+        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(n1, dim3(nwg), dim3(512), nlds, st, a));
+    } else {
+        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(k0, dim3(nwg), dim3(256), lds, st, a));
+        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(k1, dim3(nwg), dim3(256), lds, st, a));
+    }
     BALF_PROF(4 * s + 2, st, {
         hipLaunchKernelGGL(se_reduce_kernel<C>, dim3(B * kSeChunks), dim3(256), 0, st, partial, per_img, chunk);
         hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], chunk,

@@ -508,11 +508,13 @@ __global__ __launch_bounds__(256) void hn_fc_kernel(FcArgs a) {
         part[t] += __shfl_xor(part[t], 16);
         part[t] += __shfl_xor(part[t], 32);
         const int p = p0 + 16 * t + n;
-        const float inv = used[t] ? 1.0f / sqrtf(part[t] + 1e-10f) : 0.0f;        // masked slots: zero descriptors
+        const float inv = 1.0f / sqrtf(part[t] + 1e-10f);
         if (p < a.n_patches) {
+            // masked slots get exact zeros: their accumulators were fed stale workspace contents (possibly NaN/Inf)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-                *reinterpret_cast<f4 *>(a.desc + (size_t)p * kDesc + 16 * m + 4 * g) = acc[m][t] * inv;
+                *reinterpret_cast<f4 *>(a.desc + (size_t)p * kDesc + 16 * m + 4 * g) =
+                    used[t] ? acc[m][t] * inv : f4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     }
 }

@@ -116,3 +116,21 @@ def test_plain_f16_mode(hardnet):
     m.precision = "bf16"
     with pytest.raises(ValueError):
         m(x[:2].to("cuda:0"))
+
+
+def test_masked_slots_are_exact_zeros_even_over_poisoned_workspace(hardnet):
+    """Unused slots read stale workspace memory inside a partially used GEMM tile; whatever is there (NaN here), their
+    descriptors must be exact zeros and the used slots unaffected."""
+    from balf_amd import ops
+    b, k = 3, 200
+    x = synth.synthetic_patches(b * k, 5).view(b, k, 1, 32, 32).to("cuda:0")
+    count = torch.tensor([200, 37, 0], dtype=torch.int32)
+    with torch.inference_mode():
+        full = hardnet(x.view(b * k, 1, 32, 32)).view(b, k, 128)
+        ws = ops._workspace("hardnet", x.device, 1)
+        ws.view(torch.float32)[: ws.numel() // 4].fill_(float("nan"))          # poison the scratch
+        d = hardnet.forward_slots(x, count)
+    assert not torch.isnan(d).any()
+    for i, c in enumerate(count.tolist()):
+        assert torch.equal(d[i, :c], full[i, :c])
+        assert bool((d[i, c:] == 0).all())
