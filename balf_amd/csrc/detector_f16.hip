@@ -811,9 +811,29 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
 #ifndef BALF_NS256
 #define BALF_NS256 1
 #endif
+#ifndef BALF_NS128
+#define BALF_NS128 1
+#endif
+// Ring geometry: a unit carries HT row tiles per half.  C = 256: HT = 4 (8 tiles, 16 KiB; every wave DMAs one tile, hi
+// and lo).  C = 128: HT = 2 (4 tiles, 8 KiB; every wave DMAs half a tile), which keeps the workgroup under 80 KiB of
+// LDS so that two of them (16 waves) share a CU.
 constexpr int kNsRingSlots = 4;
-constexpr int kNsRingSlotBytes = 8 * 2048;
-constexpr int kNsRingBytes = kNsRingSlots * kNsRingSlotBytes;
+template <int HT> constexpr int ns_slot_bytes() { return 2 * HT * 2048; }
+template <int HT> constexpr int ns_ring_bytes() { return kNsRingSlots * ns_slot_bytes<HT>(); }
+template <int C> constexpr int ns_ht() { return C >= 256 ? 4 : 2; }
+
+template <int HT>
+__device__ __forceinline__ void ring_wait_barrier_ns(int after /* units issued after the awaited one */) {
+    // DMA instructions per unit and wave: 2 (HT = 4) or 1 (HT = 2)
+    if (after <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (HT == 4) {
+        if (after == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        if (after == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
 
 struct RingGemmNs {
     const char *wbase;
@@ -835,7 +855,9 @@ __device__ __forceinline__ RingChainNs make_chain_ns(const RingGemmNs &g0, const
     return c;
 }
 
-// wave8 (0..7) fetches row tile (wave8 & 3) of half (wave8 >> 2) of chain-relative unit t
+// HT = 4: wave8 fetches row tile (wave8 & 3) of half (wave8 >> 2) of chain-relative unit t, both parts;
+// HT = 2: tile slot j = wave8 >> 1 (half j >> 1, tile j & 1), part wave8 & 1 (hi or lo).
+template <int HT>
 __device__ __forceinline__ void chain_issue_ns(const RingChainNs &c, unsigned char *ring, int t, int slot, int wave8,
                                                int lane) {
     RingGemmNs d = c.g[0];
@@ -853,42 +875,62 @@ __device__ __forceinline__ void chain_issue_ns(const RingChainNs &c, unsigned ch
         }
     if (!valid) return;
     const int cc = t / d.ksn, k = t - cc * d.ksn;
-    const int tile = d.wnt0 + (wave8 >> 2) * d.half_tiles + cc * 4 + (wave8 & 3);
+    const int j = HT == 4 ? wave8 : (wave8 >> 1);                       // tile slot of the unit
+    int tile;
+    if (d.half_tiles == 0) tile = d.wnt0 + (j & 3);                     // token-mix matrix: its 4 row tiles (HT = 4: twice)
+    else tile = d.wnt0 + (j / HT) * d.half_tiles + cc * HT + (j % HT);
     const char *src = d.wbase + ((size_t)tile * d.KStot + d.ks0 + k) * 2048 + lane * 16;
-    unsigned char *dst = ring + slot * kNsRingSlotBytes + wave8 * 2048;
-    __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_void *)(src + 1024), (lds_void *)(dst + 1024), 16, 0, 0);
+    unsigned char *dst = ring + slot * ns_slot_bytes<HT>() + j * 2048;
+    if constexpr (HT == 4) {
+        __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(src + 1024), (lds_void *)(dst + 1024), 16, 0, 0);
+    } else {
+        const int part = (wave8 & 1) * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void *)(src + part), (lds_void *)(dst + part), 16, 0, 0);
+    }
 }
 
-template <int NTL, int CI, int P, typename BL>
+template <int NTL, int HT, int CI, int P, typename BL>
 __device__ __forceinline__ void chain_chunk_ns(f4 (&acc)[NTL][P], const RingChainNs &c, unsigned char *ring, int gu,
                                                int lane, int wave8, int hh, BL bload) {
-    if constexpr (CI * 4 < NTL) {
+    if constexpr (CI * HT < NTL) {
         const int ksn = c.g[0].ksn;
         const int later = c.tot[1] + c.tot[2] + c.tot[3];
         for (int k = 0; k < ksn; ++k) {
             const int u = CI * ksn + k;
-            ring_wait_barrier(c.tot[0] - 1 - u + later);
-            chain_issue_ns(c, ring, u + kNsRingSlots - 1, (gu + u + kNsRingSlots - 1) & (kNsRingSlots - 1), wave8, lane);
-            HL a[4], b[P];
-            const unsigned char *sl = ring + ((gu + u) & (kNsRingSlots - 1)) * kNsRingSlotBytes + hh * 8192 + lane * 16;
+            ring_wait_barrier_ns<HT>(c.tot[0] - 1 - u + later);
+            chain_issue_ns<HT>(c, ring, u + kNsRingSlots - 1, (gu + u + kNsRingSlots - 1) & (kNsRingSlots - 1), wave8, lane);
+            HL a[HT], b[P];
+            const unsigned char *sl =
+                ring + ((gu + u) & (kNsRingSlots - 1)) * ns_slot_bytes<HT>() + hh * (HT * 2048) + lane * 16;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < HT; ++nt) {
                 a[nt].hi = *reinterpret_cast<const h8 *>(sl + nt * 2048);
                 a[nt].lo = *reinterpret_cast<const h8 *>(sl + nt * 2048 + 1024);
             }
 #pragma unroll
             for (int p = 0; p < P; ++p) b[p] = bload(k, p);
-            ring_mfma<NTL, CI, P>(acc, a, b);
+#pragma unroll
+            for (int nt = 0; nt < HT; ++nt)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[CI * HT + nt][p] = mfma16(a[nt].lo, b[p].hi, acc[CI * HT + nt][p]);
+#pragma unroll
+            for (int nt = 0; nt < HT; ++nt)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[CI * HT + nt][p] = mfma16(a[nt].hi, b[p].lo, acc[CI * HT + nt][p]);
+#pragma unroll
+            for (int nt = 0; nt < HT; ++nt)
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[CI * HT + nt][p] = mfma16(a[nt].hi, b[p].hi, acc[CI * HT + nt][p]);
         }
-        chain_chunk_ns<NTL, CI + 1, P>(acc, c, ring, gu, lane, wave8, hh, bload);
+        chain_chunk_ns<NTL, HT, CI + 1, P>(acc, c, ring, gu, lane, wave8, hh, bload);
     }
 }
 
-template <int NTL, int P, typename BL>
+template <int NTL, int HT, int P, typename BL>
 __device__ __forceinline__ void gemm16_chain_ns(f4 (&acc)[NTL][P], const RingChainNs &c, int &gu, int lane, int wave8,
                                                 int hh, unsigned char *ring, BL bload) {
-    chain_chunk_ns<NTL, 0, P>(acc, c, ring, gu, lane, wave8, hh, bload);
+    chain_chunk_ns<NTL, HT, 0, P>(acc, c, ring, gu, lane, wave8, hh, bload);
     gu += c.tot[0];
 }
 
@@ -919,16 +961,17 @@ __device__ __forceinline__ void ln_stats_ns(const f4 (&x)[NTL][1], float *lnx, i
     rstd = __builtin_amdgcn_rsqf((lnx[128 + (pg * 2) * 16 + li] + lnx[128 + (pg * 2 + 1) * 16 + li]) * inv_c + kLnEps);
 }
 
+template <int C>
 constexpr int ns_lds_bytes() {
-    constexpr int C = 256;
     constexpr int slots = 4 * (C / 32) * 2048;                 // one B-operand slot per pixel tile (shared by a pair)
     constexpr int bt = 2 * C * kBtPitch16 * 2;
-    return (slots > bt ? slots : bt) + 4 * C * 4 + kNsRingBytes + par_floats<C>() * 4 + 256 * 4;
+    return (slots > bt ? slots : bt) + 4 * C * 4 + ns_ring_bytes<ns_ht<C>()>() + par_floats<C>() * 4 + 256 * 4;
 }
 
-template <int CIN, int MODE>
-__global__ __launch_bounds__(512, 1) void stage_branch_kernel16_ns(StageArgs A) {
-    constexpr int C = 256, P = 1, NT = 16, NTL = 8, KS = 8, KSL = 4;
+template <int C, int CIN, int MODE>
+__global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16_ns(StageArgs A) {   // waves per SIMD
+    constexpr int P = 1, NT = C / 16, NTL = NT / 2, KS = C / 32, KSL = KS / 2, HT = ns_ht<C>();
+    constexpr int kNsRingBytes = ns_ring_bytes<HT>(), kNsRingSlotBytes = ns_slot_bytes<HT>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int slots_b = 4 * KS * 2048, bt_b = 2 * C * kBtPitch16 * 2;
     constexpr int main_bytes = slots_b > bt_b ? slots_b : bt_b;
@@ -965,19 +1008,19 @@ __global__ __launch_bounds__(512, 1) void stage_branch_kernel16_ns(StageArgs A) 
     const char *bb = reinterpret_cast<const char *>(blob);
     RingGemmNs seq[NG + 3];
     {
-        constexpr int CH = NTL / 4, KI = CIN / 32, HT = NT / 2;
+        constexpr int CH = NTL / HT, KI = CIN / 32, HTD = NT / 2;
         int i = 0;
-        seq[i++] = RingGemmNs{bb + (size_t)S.conv0_w * 4, 0, KI, 0, KI, CH, HT};
-        seq[i++] = RingGemmNs{bb + (size_t)S.q1_w * 4, MODE * NT, KS, 0, KS, CH, HT};
-        seq[i++] = RingGemmNs{bb + (size_t)Br.d1_w * 4, 0, KS, 0, KS, CH, HT};
-        seq[i++] = RingGemmNs{bb + (size_t)Br.d1_w * 4, NT, KS, 0, KS, CH, HT};
+        seq[i++] = RingGemmNs{bb + (size_t)S.conv0_w * 4, 0, KI, 0, KI, CH, HTD};
+        seq[i++] = RingGemmNs{bb + (size_t)S.q1_w * 4, MODE * NT, KS, 0, KS, CH, HTD};
+        seq[i++] = RingGemmNs{bb + (size_t)Br.d1_w * 4, 0, KS, 0, KS, CH, HTD};
+        seq[i++] = RingGemmNs{bb + (size_t)Br.d1_w * 4, NT, KS, 0, KS, CH, HTD};
         seq[i++] = RingGemmNs{bb + (size_t)Br.mix_w * 4, 0, 2, 0, 2, 1, 0};        // 64x64 token-mix matrix: 2 units
-        seq[i++] = RingGemmNs{bb + (size_t)Br.d2_w * 4, 0, KS, 0, KS, CH, HT};
+        seq[i++] = RingGemmNs{bb + (size_t)Br.d2_w * 4, 0, KS, 0, KS, CH, HTD};
         if (MODE == 1) {
-            seq[i++] = RingGemmNs{bb + (size_t)S.q2_w * 4, 0, 2 * KS, KS, KS, CH, HT};
-            seq[i++] = RingGemmNs{bb + (size_t)S.q2_w * 4, 0, 2 * KS, 0, KS, CH, HT};
-            seq[i++] = RingGemmNs{bb + (size_t)S.r1_w * 4, 0, KS, 0, KS, CH, HT};
-            seq[i++] = RingGemmNs{bb + (size_t)S.r2_w * 4, 0, KS, 0, KS, CH, HT};
+            seq[i++] = RingGemmNs{bb + (size_t)S.q2_w * 4, 0, 2 * KS, KS, KS, CH, HTD};
+            seq[i++] = RingGemmNs{bb + (size_t)S.q2_w * 4, 0, 2 * KS, 0, KS, CH, HTD};
+            seq[i++] = RingGemmNs{bb + (size_t)S.r1_w * 4, 0, KS, 0, KS, CH, HTD};
+            seq[i++] = RingGemmNs{bb + (size_t)S.r2_w * 4, 0, KS, 0, KS, CH, HTD};
         }
     }
     seq[NG] = seq[0]; seq[NG + 1] = seq[0]; seq[NG + 2] = seq[0];
@@ -998,7 +1041,7 @@ __global__ __launch_bounds__(512, 1) void stage_branch_kernel16_ns(StageArgs A) 
     {
         const RingChainNs c0 = make_chain_ns(seq[0], seq[1], seq[2], seq[3], NG);
 #pragma unroll
-        for (int t = 0; t < kNsRingSlots - 1; ++t) chain_issue_ns(c0, ring, t, t, wave8, lane);
+        for (int t = 0; t < kNsRingSlots - 1; ++t) chain_issue_ns<HT>(c0, ring, t, t, wave8, lane);
     }
     {
         auto put = [&](int dst, int src, int n_) {
@@ -1022,7 +1065,7 @@ __global__ __launch_bounds__(512, 1) void stage_branch_kernel16_ns(StageArgs A) 
     auto G = [&](auto idx, auto &acc, auto bload) {
         constexpr int I = decltype(idx)::value;
         const RingChainNs c = make_chain_ns(seq[I], seq[I + 1], seq[I + 2], seq[I + 3], NG - I);
-        gemm16_chain_ns<NTL, P>(acc, c, gu, lane, wave8, hh, ring, bload);
+        gemm16_chain_ns<NTL, HT, P>(acc, c, gu, lane, wave8, hh, ring, bload);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -1112,11 +1155,11 @@ __global__ __launch_bounds__(512, 1) void stage_branch_kernel16_ns(StageArgs A) 
             w.hi = *reinterpret_cast<const h8 *>(sl);
             w.lo = *reinterpret_cast<const h8 *>(sl + 1024);
         };
-        ring_wait_barrier(1 + later);
-        chain_issue_ns(c, ring, kNsRingSlots - 1, (gu + kNsRingSlots - 1) & (kNsRingSlots - 1), wave8, lane);
+        ring_wait_barrier_ns<HT>(1 + later);
+        chain_issue_ns<HT>(c, ring, kNsRingSlots - 1, (gu + kNsRingSlots - 1) & (kNsRingSlots - 1), wave8, lane);
         rd(w0, gu);
-        ring_wait_barrier(later);
-        chain_issue_ns(c, ring, kNsRingSlots, (gu + kNsRingSlots) & (kNsRingSlots - 1), wave8, lane);
+        ring_wait_barrier_ns<HT>(later);
+        chain_issue_ns<HT>(c, ring, kNsRingSlots, (gu + kNsRingSlots) & (kNsRingSlots - 1), wave8, lane);
         rd(w1, gu + 1);
         gu += 2;
         const float mb1 = par[kParMixB * C + tok] + 1.0f;
@@ -1314,11 +1357,11 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
                 hipSuccess)
             return BALF_ERR_LAUNCH;
     }
-    if constexpr (C == 256 && BALF_NS256 != 0) {
-        constexpr int nlds = ns_lds_bytes();
-        static_assert(nlds <= 160 * 1024, "N-split LDS image");
-        auto n0 = stage_branch_kernel16_ns<CIN, 0>;
-        auto n1 = stage_branch_kernel16_ns<CIN, 1>;
+    if constexpr ((C == 256 && BALF_NS256 != 0) || (C == 128 && BALF_NS128 != 0)) {
+        constexpr int nlds = ns_lds_bytes<C>();
+        static_assert(nlds <= (C >= 256 ? 160 : 80) * 1024, "N-split LDS image");
+        auto n0 = stage_branch_kernel16_ns<C, CIN, 0>;
+        auto n1 = stage_branch_kernel16_ns<C, CIN, 1>;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(n0), hipFuncAttributeMaxDynamicSharedMemorySize, nlds) !=
                 hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(n1), hipFuncAttributeMaxDynamicSharedMemorySize, nlds) !=
