@@ -814,6 +814,9 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
 #ifndef BALF_NS128
 #define BALF_NS128 1
 #endif
+#ifndef BALF_NS64
+#define BALF_NS64 0      // measured slower at C = 64 (VALU-bound kernels; half the MFMAs per barrier)
+#endif
 // Ring geometry: a unit carries HT row tiles per half.  C = 256: HT = 4 (8 tiles, 16 KiB; every wave DMAs one tile, hi
 // and lo).  C = 128: HT = 2 (4 tiles, 8 KiB; every wave DMAs half a tile), which keeps the workgroup under 80 KiB of
 // LDS so that two of them (16 waves) share a CU.
@@ -935,47 +938,58 @@ __device__ __forceinline__ void gemm16_chain_ns(f4 (&acc)[NTL][P], const RingCha
 }
 
 // LayerNorm statistics over all C channels of a pixel: this wave's half + the partner's, through LDS
-// (lnx: [which 0/1][pair 4][half 2][16 pixels]); all 8 waves call this together (two barriers).
-template <int NTL>
-__device__ __forceinline__ void ln_stats_ns(const f4 (&x)[NTL][1], float *lnx, int pg, int hh, int q, int li, float &mean,
-                                            float &rstd) {
+// (lnx: [which 0/1][pair 4][half 2][P][16 pixels]); all 8 waves call this together (two barriers).
+template <int NTL, int P>
+__device__ __forceinline__ void ln_stats_ns(const f4 (&x)[NTL][P], float *lnx, int pg, int hh, int q, int li,
+                                            float (&mean)[P], float (&rstd)[P]) {
     constexpr float inv_c = 1.0f / (32 * NTL);
-    float s = 0.0f;
 #pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) s += (x[nt][0][0] + x[nt][0][1]) + (x[nt][0][2] + x[nt][0][3]);
-    s = quarter_allreduce(s);
-    if (q == 0) lnx[(pg * 2 + hh) * 16 + li] = s;
+    for (int p = 0; p < P; ++p) {
+        float s = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) s += (x[nt][p][0] + x[nt][p][1]) + (x[nt][p][2] + x[nt][p][3]);
+        s = quarter_allreduce(s);
+        if (q == 0) lnx[((pg * 2 + hh) * P + p) * 16 + li] = s;
+    }
     lds_barrier();
-    mean = (lnx[(pg * 2) * 16 + li] + lnx[(pg * 2 + 1) * 16 + li]) * inv_c;
-    float v = 0.0f;
 #pragma unroll
-    for (int nt = 0; nt < NTL; ++nt)
+    for (int p = 0; p < P; ++p) {
+        mean[p] = (lnx[((pg * 2) * P + p) * 16 + li] + lnx[((pg * 2 + 1) * P + p) * 16 + li]) * inv_c;
+        float v = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float d = x[nt][0][r] - mean;
-            v = fmaf(d, d, v);
-        }
-    v = quarter_allreduce(v);
-    if (q == 0) lnx[128 + (pg * 2 + hh) * 16 + li] = v;
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = x[nt][p][r] - mean[p];
+                v = fmaf(d, d, v);
+            }
+        v = quarter_allreduce(v);
+        if (q == 0) lnx[128 * P + ((pg * 2 + hh) * P + p) * 16 + li] = v;
+    }
     lds_barrier();
-    rstd = __builtin_amdgcn_rsqf((lnx[128 + (pg * 2) * 16 + li] + lnx[128 + (pg * 2 + 1) * 16 + li]) * inv_c + kLnEps);
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        rstd[p] = __builtin_amdgcn_rsqf((lnx[128 * P + ((pg * 2) * P + p) * 16 + li] +
+                                         lnx[128 * P + ((pg * 2 + 1) * P + p) * 16 + li]) * inv_c + kLnEps);
 }
 
 template <int C>
 constexpr int ns_lds_bytes() {
-    constexpr int slots = 4 * (C / 32) * 2048;                 // one B-operand slot per pixel tile (shared by a pair)
-    constexpr int bt = 2 * C * kBtPitch16 * 2;
-    return (slots > bt ? slots : bt) + 4 * C * 4 + ns_ring_bytes<ns_ht<C>()>() + par_floats<C>() * 4 + 256 * 4;
+    constexpr int P = StageP<C>::P;
+    constexpr int slots = 4 * (C / 32) * P * 2048;             // one B-operand slot per pixel tile (shared by a pair)
+    constexpr int bt = 2 * P * C * kBtPitch16 * 2;
+    return (slots > bt ? slots : bt) + 4 * C * 4 + ns_ring_bytes<ns_ht<C>()>() + par_floats<C>() * 4 + 256 * P * 4;
 }
 
 template <int C, int CIN, int MODE>
 __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16_ns(StageArgs A) {   // waves per SIMD
-    constexpr int P = 1, NT = C / 16, NTL = NT / 2, KS = C / 32, KSL = KS / 2, HT = ns_ht<C>();
+    constexpr int P = StageP<C>::P, NT = C / 16, NTL = NT / 2, KS = C / 32, KSL = KS / 2, HT = ns_ht<C>();
     constexpr int kNsRingBytes = ns_ring_bytes<HT>(), kNsRingSlotBytes = ns_slot_bytes<HT>();
+    static_assert(KSL >= 1 && NTL % HT == 0, "N-split geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int slots_b = 4 * KS * 2048, bt_b = 2 * C * kBtPitch16 * 2;
+    constexpr int slots_b = 4 * KS * P * 2048, bt_b = 2 * P * C * kBtPitch16 * 2;
     constexpr int main_bytes = slots_b > bt_b ? slots_b : bt_b;
-    _Float16 *bT = reinterpret_cast<_Float16 *>(smem_raw);                 // [hi|lo][c][pitch]
+    _Float16 *bT = reinterpret_cast<_Float16 *>(smem_raw);                 // [hi|lo][p][c][pitch]
     float *red = reinterpret_cast<float *>(smem_raw + main_bytes);         // [4][C]
     unsigned char *ring = smem_raw + main_bytes + 4 * C * 4;
     float *par = reinterpret_cast<float *>(smem_raw + main_bytes + 4 * C * 4 + kNsRingBytes);
@@ -984,25 +998,29 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     const int lane = threadIdx.x & 63, wave8 = threadIdx.x >> 6, q = lane >> 4, li = lane & 15;
     const int pg = wave8 >> 1, hh = wave8 & 1;         // pixel tile of the token group, channel half
     const int nt0 = hh * NTL, ks0 = hh * KSL;
-    h8 *slot = reinterpret_cast<h8 *>(smem_raw) + pg * (KS * 2 * 64);     // [ks][hi|lo][lane], shared by the pair
+    h8 *slot = reinterpret_cast<h8 *>(smem_raw) + pg * (KS * P * 2 * 64);  // [ks][p][hi|lo][lane], shared by the pair
     const float *blob = A.blob;
     const StageOff &S = A.off;
     const BranchOff &Br = S.br[MODE];
 
     const int H = A.H, W = A.W;
-    const int cols = W / 8;
+    const int cols = W / 8 / P;
     const int per_img = (H / 8) * cols;
     const int nwg = gridDim.x;
     const int xq = nwg >> 3, xr = nwg & 7, xl = blockIdx.x & 7, xj = blockIdx.x >> 3;
     const int item = (xl < xr ? xl * (xq + 1) : xr * (xq + 1) + (xl - xr) * xq) + xj;
     const int n = item / per_img;
     const int rem = item - n * per_img;
-    const int iy0 = rem / cols, ix0 = rem - iy0 * cols;
+    const int iy0 = rem / cols, ix0 = (rem - iy0 * cols) * P;
     const int tok = 16 * pg + li, ty = tok >> 3, tx = tok & 7;
-    int y, x;
-    if (MODE == 0) { y = ty * (H / 8) + iy0; x = tx * (W / 8) + ix0; }
-    else           { y = 8 * iy0 + ty;       x = 8 * ix0 + tx; }
-    const long pix = ((long)n * H + y) * W + x;
+    long pix[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int y, x;
+        if (MODE == 0) { y = ty * (H / 8) + iy0; x = tx * (W / 8) + ix0 + p; }
+        else           { y = 8 * iy0 + ty;       x = 8 * (ix0 + p) + tx; }
+        pix[p] = ((long)n * H + y) * W + x;
+    }
 
     constexpr int NG = (MODE == 0) ? 6 : 10;
     const char *bb = reinterpret_cast<const char *>(blob);
@@ -1026,16 +1044,24 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     seq[NG] = seq[0]; seq[NG + 1] = seq[0]; seq[NG + 2] = seq[0];
     int gu = 0;
 
-    // ---- prologue: stage input (this wave's half of the K-steps) -> shared slot, ring prime, parameter cache ----
+    // ---- prologue: stage input (K-steps split between the pair) -> shared slot, ring prime, parameter cache ----
     {
-        constexpr int KIH = CIN / 32 / 2;
-        HL xin[KIH];
+        constexpr int KI = CIN / 32;
+        constexpr int KIH = KI >= 2 ? KI / 2 : 1;
+        const int kbase = KI >= 2 ? hh * KIH : 0;
+        if (KI >= 2 || hh == 0) {
+            HL xin[KIH][P];
 #pragma unroll
-        for (int kk = 0; kk < KIH; ++kk) xin[kk] = load_frag_px(A.X, pix, CIN, hh * KIH + kk, q);
+            for (int kk = 0; kk < KIH; ++kk)
 #pragma unroll
-        for (int kk = 0; kk < KIH; ++kk) {
-            slot[((hh * KIH + kk) * 2 + 0) * 64 + lane] = xin[kk].hi;
-            slot[((hh * KIH + kk) * 2 + 1) * 64 + lane] = xin[kk].lo;
+                for (int p = 0; p < P; ++p) xin[kk][p] = load_frag_px(A.X, pix[p], CIN, kbase + kk, q);
+#pragma unroll
+            for (int kk = 0; kk < KIH; ++kk)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    slot[(((kbase + kk) * P + p) * 2 + 0) * 64 + lane] = xin[kk][p].hi;
+                    slot[(((kbase + kk) * P + p) * 2 + 1) * 64 + lane] = xin[kk][p].lo;
+                }
         }
     }
     {
@@ -1072,26 +1098,29 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     using I5 = std::integral_constant<int, 5>;
     using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
     using I8 = std::integral_constant<int, 8>; using I9 = std::integral_constant<int, 9>;
-    auto from_slot = [&](int kk, int) {
+    auto from_slot = [&](int kk, int p) {
         HL o;
-        o.hi = slot[(kk * 2 + 0) * 64 + lane];
-        o.lo = slot[(kk * 2 + 1) * 64 + lane];
+        o.hi = slot[((kk * P + p) * 2 + 0) * 64 + lane];
+        o.lo = slot[((kk * P + p) * 2 + 1) * 64 + lane];
         return o;
     };
-    // this wave's 8 tiles are K-steps ks0 .. ks0+3 of the next Linear; the barrier in front keeps the partner's (and
+    // this wave's tiles are K-steps ks0 .. ks0+KSL-1 of the next Linear; the barrier in front keeps the partner's (and
     // this wave's) reads of the previous contents ahead of the overwrite, the ring's first barrier publishes it
     auto to_slot = [&](const f4 (&t)[NTL][P]) {
         lds_barrier();
-        store_slot16(slot + ks0 * (2 * 64), t, lane);
+        store_slot16(slot + ks0 * (P * 2 * 64), t, lane);
     };
     auto ln_plain = [&](const f4 (&xin_)[NTL][P], f4 (&yout)[NTL][P]) {
-        float mean, rstd;
-        ln_stats_ns<NTL>(xin_, lnx, pg, hh, q, li, mean, rstd);
-        const float shift = -mean * rstd;
+        float mean[P], rstd[P];
+        ln_stats_ns<NTL, P>(xin_, lnx, pg, hh, q, li, mean, rstd);
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt)
+        for (int p = 0; p < P; ++p) {
+            const float shift = -mean[p] * rstd[p];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) yout[nt][0][r] = fmaf(xin_[nt][0][r], rstd, shift);
+            for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yout[nt][p][r] = fmaf(xin_[nt][p][r], rstd[p], shift);
+        }
     };
 
     // ---- x0 = relu(conv0(X)) ----
@@ -1123,26 +1152,30 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
         G(I3{}, gb, from_slot);
         gelu<false>(gb);
         {
-            float mean, rstd;
-            ln_stats_ns<NTL>(gb, lnx, pg, hh, q, li, mean, rstd);
+            float mean[P], rstd[P];
+            ln_stats_ns<NTL, P>(gb, lnx, pg, hh, q, li, mean, rstd);
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) {
                 const f4 gg = ldg4(par + kParGlnG * C + 16 * (nt0 + nt) + 4 * q), be = ldg4(par + kParGlnB * C + 16 * (nt0 + nt) + 4 * q);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gb[nt][0][r] = (gb[nt][0][r] - mean) * rstd * gg[r] + be[r];
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gb[nt][p][r] = (gb[nt][p][r] - mean[p]) * rstd[p] * gg[r] + be[r];
             }
         }
         lds_barrier();                                  // slots (aliased by bT) are no longer read
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) {
-            h2 h01, l01, h23, l23;
-            split_pair(gb[nt][0][0], gb[nt][0][1], h01, l01);
-            split_pair(gb[nt][0][2], gb[nt][0][3], h23, l23);
-            _Float16 *row = bT + (16 * (nt0 + nt) + 4 * q) * kBtPitch16 + tok;
-            _Float16 *rowl = row + C * kBtPitch16;
-            row[0] = h01[0]; row[kBtPitch16] = h01[1]; row[2 * kBtPitch16] = h23[0]; row[3 * kBtPitch16] = h23[1];
-            rowl[0] = l01[0]; rowl[kBtPitch16] = l01[1]; rowl[2 * kBtPitch16] = l23[0]; rowl[3 * kBtPitch16] = l23[1];
-        }
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                h2 h01, l01, h23, l23;
+                split_pair(gb[nt][p][0], gb[nt][p][1], h01, l01);
+                split_pair(gb[nt][p][2], gb[nt][p][3], h23, l23);
+                _Float16 *row = bT + (p * C + 16 * (nt0 + nt) + 4 * q) * kBtPitch16 + tok;
+                _Float16 *rowl = row + P * C * kBtPitch16;
+                row[0] = h01[0]; row[kBtPitch16] = h01[1]; row[2 * kBtPitch16] = h23[0]; row[3 * kBtPitch16] = h23[1];
+                rowl[0] = l01[0]; rowl[kBtPitch16] = l01[1]; rowl[2 * kBtPitch16] = l23[0]; rowl[3 * kBtPitch16] = l23[1];
+            }
     }
     lds_barrier();
     {
@@ -1164,50 +1197,63 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
         gu += 2;
         const float mb1 = par[kParMixB * C + tok] + 1.0f;
 #pragma unroll
-        for (int ct = 0; ct < NTL; ++ct) {
-            const _Float16 *row = bT + (16 * (nt0 + ct) + li) * kBtPitch16 + 8 * q;
-            const _Float16 *rowl = row + C * kBtPitch16;
-            HL a0, a1;
-            a0.hi = *reinterpret_cast<const h8 *>(row);      a0.lo = *reinterpret_cast<const h8 *>(rowl);
-            a1.hi = *reinterpret_cast<const h8 *>(row + 32); a1.lo = *reinterpret_cast<const h8 *>(rowl + 32);
-            f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
-            m = mfma16x3(a0, w0, m);
-            m = mfma16x3(a1, w1, m);
+        for (int p = 0; p < P; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ga[ct][0][r] *= (m[r] + mb1);
-        }
+            for (int ct = 0; ct < NTL; ++ct) {
+                const _Float16 *row = bT + (p * C + 16 * (nt0 + ct) + li) * kBtPitch16 + 8 * q;
+                const _Float16 *rowl = row + P * C * kBtPitch16;
+                HL a0, a1;
+                a0.hi = *reinterpret_cast<const h8 *>(row);      a0.lo = *reinterpret_cast<const h8 *>(rowl);
+                a1.hi = *reinterpret_cast<const h8 *>(row + 32); a1.lo = *reinterpret_cast<const h8 *>(rowl + 32);
+                f4 m = {0.0f, 0.0f, 0.0f, 0.0f};
+                m = mfma16x3(a0, w0, m);
+                m = mfma16x3(a1, w1, m);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ga[ct][p][r] *= (m[r] + mb1);
+            }
     }
     to_slot(ga);                                        // (its barrier also ends the reads of bT)
     f4 o[NTL][P];
     init_bias(o, par + kParD2B * C + 16 * nt0, q);
     G(I5{}, o, from_slot);
 #pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) o[nt][0] += z[nt][0];
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; ++p) o[nt][p] += z[nt][p];
 
     if constexpr (MODE == 0) {
 #pragma unroll
-        for (int ks = 0; ks < KSL; ++ks) store_frag_px(A.U, pix, C, ks0 + ks, q, split8(o[2 * ks][0], o[2 * ks + 1][0]));
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int ks = 0; ks < KSL; ++ks)
+                store_frag_px(A.U, pix[p], C, ks0 + ks, q, split8(o[2 * ks][p], o[2 * ks + 1][p]));
         return;
     } else {
-        HL ub[KSL];                                     // this wave's half of the u' K-steps, in flight during G(I6)
+        HL ub[KSL][P];                                  // this wave's half of the u' K-steps, in flight during G(I6)
 #pragma unroll
-        for (int kk = 0; kk < KSL; ++kk) ub[kk] = load_frag_px(A.U, pix, C, ks0 + kk, q);
+        for (int kk = 0; kk < KSL; ++kk)
+#pragma unroll
+            for (int p = 0; p < P; ++p) ub[kk][p] = load_frag_px(A.U, pix[p], C, ks0 + kk, q);
         to_slot(o);
         f4 x1[NTL][P];
         init_bias(x1, par + kParQ2B * C + 64 + 16 * nt0, q);
         G(I6{}, x1, from_slot);
         lds_barrier();
 #pragma unroll
-        for (int kk = 0; kk < KSL; ++kk) {
-            slot[((ks0 + kk) * 2 + 0) * 64 + lane] = ub[kk].hi;
-            slot[((ks0 + kk) * 2 + 1) * 64 + lane] = ub[kk].lo;
-        }
+        for (int kk = 0; kk < KSL; ++kk)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                slot[(((ks0 + kk) * P + p) * 2 + 0) * 64 + lane] = ub[kk][p].hi;
+                slot[(((ks0 + kk) * P + p) * 2 + 1) * 64 + lane] = ub[kk][p].lo;
+            }
         G(I7{}, x1, from_slot);
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) {
-            x1[nt][0] += x0[nt][0];
-            *reinterpret_cast<f4 *>(A.R + pix * C + 16 * (nt0 + nt) + 4 * q) = x1[nt][0] + x0[nt][0];
-        }
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                x1[nt][p] += x0[nt][p];
+                *reinterpret_cast<f4 *>(A.R + pix[p] * C + 16 * (nt0 + nt) + 4 * q) = x1[nt][p] + x0[nt][p];
+            }
         ln_plain(x1, x1);
         to_slot(x1);
         f4 m1[NTL][P];
@@ -1220,10 +1266,15 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
         G(I9{}, t, from_slot);
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
-            *reinterpret_cast<f4 *>(A.T + pix * C + 16 * (nt0 + nt) + 4 * q) = t[nt][0];
+            f4 ssum = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                *reinterpret_cast<f4 *>(A.T + pix[p] * C + 16 * (nt0 + nt) + 4 * q) = t[nt][p];
+                ssum += t[nt][p];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = t[nt][0][r];
+                float v = ssum[r];
                 v += __shfl_xor(v, 1, 64);
                 v += __shfl_xor(v, 2, 64);
                 v += __shfl_xor(v, 4, 64);
@@ -1357,7 +1408,7 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
                 hipSuccess)
             return BALF_ERR_LAUNCH;
     }
-    if constexpr ((C == 256 && BALF_NS256 != 0) || (C == 128 && BALF_NS128 != 0)) {
+    if constexpr ((C == 256 && BALF_NS256 != 0) || (C == 128 && BALF_NS128 != 0) || (C == 64 && BALF_NS64 != 0)) {
         constexpr int nlds = ns_lds_bytes<C>();
         static_assert(nlds <= (C >= 256 ? 160 : 80) * 1024, "N-split LDS image");
         auto n0 = stage_branch_kernel16_ns<C, CIN, 0>;
