@@ -97,3 +97,58 @@ def extract_matches(args, im_rgb1, im_gray1, im_rgb2, im_gray2, detector, descri
         _, match_ids = ops.match_smnn(torch.from_numpy(desc1).to(device), torch.from_numpy(desc2).to(device), 0.99)
     match_ids = match_ids.cpu().numpy()
     return kpts1[match_ids[:, 0], :2], kpts2[match_ids[:, 1], :2]
+
+
+def load_im(im_path):
+    """demo_match.py:13-19: (RGB uint8 [H,W,3], gray uint8 [H,W]) via PIL."""
+    from PIL import Image
+    im_rgb = Image.open(im_path).convert('RGB')
+    return np.array(im_rgb), np.array(im_rgb.convert('L'))
+
+
+def draw_matches(im1, kpts1, im2, kpts2):
+    """Side-by-side canvas with one line per match (the reference draws with cv2.drawMatches, demo_match.py:114-118;
+    cv2 is not a dependency here, PIL is)."""
+    from PIL import Image, ImageDraw
+    h = max(im1.shape[0], im2.shape[0])
+    canvas = Image.new('RGB', (im1.shape[1] + im2.shape[1], h))
+    canvas.paste(Image.fromarray(im1), (0, 0))
+    canvas.paste(Image.fromarray(im2), (im1.shape[1], 0))
+    d = ImageDraw.Draw(canvas)
+    for (x1, y1), (x2, y2) in zip(kpts1, kpts2):
+        d.line([(float(x1), float(y1)), (float(x2) + im1.shape[1], float(y2))], fill=(0, 255, 0), width=1)
+    return np.array(canvas)
+
+
+def main(argv=None):
+    """The reference demo's ``__main__`` (demo_match.py:120-147) as a command:
+    python -m balf_amd.demo.demo_match --ckpt_file balf.pth --ckpt_descriptor_file HardNet++.pth im1.jpg im2.jpg out.png"""
+    import argparse
+    from ..model import get_model
+    from ..third_party.hardnet.hardnet_pytorch import HardNet
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument('--ckpt_file', required=True)
+    ap.add_argument('--ckpt_descriptor_file', required=True)
+    ap.add_argument('--descriptor_precision', default='fp16-split', choices=['fp16-split', 'fp16'])
+    ap.add_argument('--detector_precision', default='fp32', choices=['fp32', 'fp16'])
+    ap.add_argument('image1'); ap.add_argument('image2'); ap.add_argument('output')
+    a = ap.parse_args(argv)
+    device = torch.device('cuda')
+    detector = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    get_model.load_test_pretrained_model(model=detector, filename=a.ckpt_file)
+    detector.precision = a.detector_precision
+    detector = detector.eval().to(device)
+    descriptor = HardNet()
+    descriptor.load_state_dict(torch.load(a.ckpt_descriptor_file, weights_only=True)['state_dict'])
+    descriptor.precision = a.descriptor_precision
+    descriptor = descriptor.eval().to(device)
+    im_rgb1, im_gray1 = load_im(a.image1)
+    im_rgb2, im_gray2 = load_im(a.image2)
+    m1, m2 = extract_matches(DEFAULT_ARGS, im_rgb1, im_gray1, im_rgb2, im_gray2, detector, descriptor, device)
+    from PIL import Image
+    Image.fromarray(draw_matches(im_rgb1, m1, im_rgb2, m2)).save(a.output)
+    print(f"{len(m1)} matches -> {a.output}")
+
+
+if __name__ == "__main__":
+    main()

@@ -212,3 +212,18 @@ def test_batched_rgb_input(models):
     gray = ops.rgb_to_gray_u8(rgb)
     xy2, desc2, count2 = demo_match.detect_and_describe_batch(demo_match.DEFAULT_ARGS, rgb, det, hn, gray_u8=gray)
     assert torch.equal(xy, xy2) and torch.equal(desc, desc2) and torch.equal(count, count2)
+
+
+def test_demo_command_line(tmp_path):
+    """python -m balf_amd.demo.demo_match with checkpoints and images on disk, as the reference demo is used."""
+    from PIL import Image
+    det_ckpt, hn_ckpt = tmp_path / "balf.pth", tmp_path / "HardNet++.pth"
+    torch.save({"model_state": synth.synthetic_state_dict(cases.WEIGHT_SEED)}, det_ckpt)
+    torch.save({"state_dict": synth.synthetic_hardnet_state_dict(cases.HARDNET_SEED)}, hn_ckpt)
+    for i in (1, 2):
+        g = synth.synthetic_gray_u8(180, 240, 60 + i, blur=7)
+        Image.fromarray(np.stack([g, g // 2 + 60, 255 - g], -1).astype(np.uint8)).save(tmp_path / f"im{i}.png")
+    out = tmp_path / "matches.png"
+    demo_match.main(["--ckpt_file", str(det_ckpt), "--ckpt_descriptor_file", str(hn_ckpt), "--descriptor_precision", "fp16",
+                     str(tmp_path / "im1.png"), str(tmp_path / "im2.png"), str(out)])
+    assert np.array(Image.open(out)).shape == (180, 480, 3)
