@@ -1,0 +1,22 @@
+"""Determinism soak of the f16 forward: N repetitions at full load, every result must be bit-identical to the first.
+Usage: python tools/soak.py [reps] [batch] [H] [W]"""
+import sys, torch
+sys.path.insert(0, ".")
+from balf_amd import arch
+from balf_amd.model import get_model
+from balf_amd.utils import synth
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+b = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+h = int(sys.argv[3]) if len(sys.argv) > 3 else 1088
+w = int(sys.argv[4]) if len(sys.argv) > 4 else 1920
+m = get_model.load_model(arch.DEFAULT_MODEL_CFG); m.load_state_dict(synth.synthetic_state_dict(7)); m.precision = "fp16"; m = m.eval().cuda()
+x = torch.rand((b, 3, h, w), device="cuda")
+with torch.inference_mode():
+    ref = m(x)
+    bad = 0
+    for i in range(reps):
+        o = m(x)
+        if not (torch.equal(o["prob"], ref["prob"]) and torch.equal(o["logits"], ref["logits"])):
+            bad += 1
+            print("mismatch at repetition", i, int((o["prob"] != ref["prob"]).sum()))
+print(f"{reps} repetitions of {b}x{h}x{w}: {bad} mismatches, finite={bool(torch.isfinite(ref['prob']).all())}")
