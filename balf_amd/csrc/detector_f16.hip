@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    using I5 = std::integral_constant<int, 5>;
     using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
     using I8 = std::integral_constant<int, 8>; using I9 = std::integral_constant<int, 9>;
 
