@@ -125,7 +125,14 @@ def cpu_baseline(h, w, k, n_images, state, threads=0):
             t_fwd += tb - ta
             kp += idx.size
     dt = time.perf_counter() - t0
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": n_images / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
             "keypoints_per_s": kp / dt,
             "forward_s_per_image": t_fwd / n_images, "nms_topk_s_per_image": t_nms / n_images,
             "sample": f"{n_images} synthetic {w}x{h} gray images, batch 1, oracle forward (torch CPU fp32) + C NMS/top-{k}; "
