@@ -53,12 +53,29 @@ __device__ __forceinline__ void init_bias(f4 (&t)[NT][P], const float *bias, int
     }
 }
 
-// Exact (erf) GELU, nn.GELU() default (mlp_ma_decoder.py:52,99,126): x * Phi(x), with
-// Phi(-|x|) = 0.5 * erfc(|x| / sqrt 2) from Abramowitz-Stegun 7.1.26 (|erfc error| < 1.5e-7).  Measured
-// max-abs error of the whole expression vs fp64 over [-12, 12]: 4.2e-7 (torch's own fp32 GELU: 1.2e-6).
-// ~14 VALU instructions (one v_rcp_f32, one v_exp_f32) instead of ~35 for 0.5x(1 + erff(x/sqrt 2)).
+// max(x, 0) as ONE instruction: a signed-integer max on the float's bits (negative floats, -0 included, are negative
+// integers).  fmaxf on an MFMA result costs a second v_max_f32 that only quiets NaNs (IEEE mode), and hipcc folds
+// v_med3_f32 with constants back into that pair.
+__device__ __forceinline__ float max0(float x) {
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+
+// Exact (erf) GELU, nn.GELU() default (mlp_ma_decoder.py:52,99,126): x * Phi(x) = max(x, 0) - |x| Phi(-|x|), with
+// Phi(-a) = 2^P(a), P = degree-5 polynomial fitted to log2(0.5 erfc(a / sqrt 2)) under the weight a Phi(-a) (the factor
+// its error is multiplied by).  Max-abs error of the whole expression vs fp64 over [-12, 12]: 8.6e-7 (torch's own fp32
+// GELU: 1.2e-6); the leading coefficient is negative, so large |x| underflow to the exact limits (0 and x).
+// 8 VALU instructions, ONE transcendental (v_exp_f32 issues at a quarter of the fma rate) -- the Abramowitz-Stegun
+// 7.1.26 form used before (BALF_GELU_AS=1) took 14 with two (v_rcp_f32, v_exp_f32): GELU was 45 % of the vector
+// instructions of the stage-1 kernels.
+#ifndef BALF_GELU_AS
+#define BALF_GELU_AS 0
+#endif
+constexpr float kG0 = -1.000037633e+00f, kG1 = -1.150787766e+00f, kG2 = -4.599926517e-01f, kG3 = -5.182716455e-02f,
+                kG4 = 7.084460191e-03f, kG5 = -4.732939498e-04f;
 __device__ __forceinline__ float gelu1(float x) {
     const float ax = fabsf(x);
+#if BALF_GELU_AS
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
     const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
     float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);     // coefficients pre-scaled by 1/2
@@ -67,15 +84,26 @@ __device__ __forceinline__ float gelu1(float x) {
     p = fmaf(p, t, 0.5f * 0.254829592f);
     const float y = p * t * e;                     // Phi(-|x|)
     return fmaf(ax, 0.5f - y, 0.5f * x);           // = max(x, 0) - |x| y:  x >= 0: x(1 - y);  x < 0: x y
+#else
+    float p = fmaf(kG5, ax, kG4);
+    p = fmaf(p, ax, kG3);
+    p = fmaf(p, ax, kG2);
+    p = fmaf(p, ax, kG1);
+    p = fmaf(p, ax, kG0);
+    float e = __builtin_amdgcn_exp2f(p);
+    asm("" : "+v"(e));       // opaque: keeps hipcc from pairing two of these fmas into a v_pk_fma_f32, which has no
+                             // |x| modifier and costs two extra v_or_b32 per pair
+    return fmaf(-ax, e, max0(x));
+#endif
 }
 
-// GELU on four values with the multiply/add work written as 2-wide vector math, which hipcc lowers to
-// v_pk_mul_f32 / v_pk_fma_f32 (two fp32 lanes per VALU slot; a wave64 VALU instruction occupies the SIMD for
-// 4 cycles either way, so packing halves the cost of everything but the rcp/exp2).
+// GELU on two values with the multiply/add work written as 2-wide vector math, which hipcc lowers to
+// v_pk_mul_f32 / v_pk_fma_f32 (two fp32 lanes per VALU slot).
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 gelu2(f2 x) {
     const f2 ax = {fabsf(x[0]), fabsf(x[1])};
+#if BALF_GELU_AS
     const f2 den = ax * (0.3275911f * 0.70710678118654752440f) + 1.0f;
     const f2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
     const f2 ea = x * x * (-0.5f * 1.44269504088896340736f);
@@ -86,6 +114,16 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
     p = p * t + (0.5f * 0.254829592f);
     const f2 y = p * t * e;                         // Phi(-|x|)
     return ax * (0.5f - y) + x * 0.5f;
+#else
+    f2 p = ax * kG5 + kG4;
+    p = p * ax + kG3;
+    p = p * ax + kG2;
+    p = p * ax + kG1;
+    p = p * ax + kG0;
+    const f2 e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+    const f2 m = {max0(x[0]), max0(x[1])};
+    return m - ax * e;
+#endif
 }
 
 #ifndef BALF_ABLATE_GELU
@@ -117,7 +155,7 @@ __device__ __forceinline__ void relu(f4 (&t)[NT][P]) {
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[nt][p][r] = fmaxf(t[nt][p][r], 0.0f);
+            for (int r = 0; r < 4; ++r) t[nt][p][r] = max0(t[nt][p][r]);
 }
 
 template <int NT, int P>

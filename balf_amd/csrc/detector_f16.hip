@@ -1391,13 +1391,18 @@ __global__ __launch_bounds__(256, 2) void head_kernel16(HeadArgs A) {
     }
 }
 
+#ifndef BALF_S1_WAVE
+#define BALF_S1_WAVE 1      // stage 1: persistent wave-owns-group kernels (stage1_f16.h); 0 = generic stage kernels
+#endif
+#include "stage1_f16.h"
+
 template <int C, int CIN>
 int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
                 float *partial, float *chunk, float *scale, hipStream_t st) {
     constexpr int P = StageP<C>::P;
     constexpr int lds = stage_lds_bytes16<C, P>();
     StageArgs a{blob, kLayout.st[s], X, u8.p, u8.ch, u8.h, u8.w, u8.top, u8.left, B, H, W, U, T, R, partial};
-    const int per_img = (H / 8) * (W / 8 / P);
+    int per_img = (H / 8) * (W / 8 / P);
     const int nwg = B * per_img;
     auto k0 = stage_branch_kernel16<C, CIN, 0>;
     auto k1 = stage_branch_kernel16<C, CIN, 1>;
@@ -1408,7 +1413,27 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
                 hipSuccess)
             return BALF_ERR_LAUNCH;
     }
-    if constexpr ((C == 256 && BALF_NS256 != 0) || (C == 128 && BALF_NS128 != 0) || (C == 64 && BALF_NS64 != 0)) {
+    if constexpr (C == 32 && BALF_S1_WAVE != 0) {
+        // persistent: one workgroup per CU (256 CUs on MI355X; any multiple of 8 is correct), waves loop over token groups
+        auto g0 = stage1_kernel16<0>;
+        auto g1 = stage1_kernel16<1>;
+        constexpr int l0 = s1_lds_bytes<0>(), l1 = s1_lds_bytes<1>();
+        static_assert(l0 <= 160 * 1024 && l1 <= 160 * 1024, "stage-1 LDS image");
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(g0), hipFuncAttributeMaxDynamicSharedMemorySize, l0) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(g1), hipFuncAttributeMaxDynamicSharedMemorySize, l1) !=
+                hipSuccess)
+            return BALF_ERR_LAUNCH;
+        per_img = (H / 8) * (W / 8);                       // one partial-sum row per token group
+        const long groups = (long)B * per_img;
+        auto blocks = [&](int waves) {
+            long b = (groups + waves - 1) / waves;
+            b = (b + 7) / 8 * 8;
+            return (unsigned)(b < 256 ? b : 256);
+        };
+        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(g0, dim3(blocks(s1_waves<0>())), dim3(s1_waves<0>() * 64), l0, st, a));
+        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(g1, dim3(blocks(s1_waves<1>())), dim3(s1_waves<1>() * 64), l1, st, a));
+    } else if constexpr ((C == 256 && BALF_NS256 != 0) || (C == 128 && BALF_NS128 != 0) || (C == 64 && BALF_NS64 != 0)) {
         constexpr int nlds = ns_lds_bytes<C>();
         static_assert(nlds <= (C >= 256 ? 160 : 80) * 1024, "N-split LDS image");
         auto n0 = stage_branch_kernel16_ns<C, CIN, 0>;
