@@ -1415,8 +1415,8 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
     }
     if constexpr (C == 32 && BALF_S1_WAVE != 0) {
         // persistent: one workgroup per CU (256 CUs on MI355X; any multiple of 8 is correct), waves loop over token groups
-        auto g0 = stage1_kernel16<0>;
-        auto g1 = stage1_kernel16<1>;
+        auto g0 = u8.ch ? stage1_kernel16<0, true> : stage1_kernel16<0, false>;
+        auto g1 = u8.ch ? stage1_kernel16<1, true> : stage1_kernel16<1, false>;
         constexpr int l0 = s1_lds_bytes<0>(), l1 = s1_lds_bytes<1>();
         static_assert(l0 <= 160 * 1024 && l1 <= 160 * 1024, "stage-1 LDS image");
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(g0), hipFuncAttributeMaxDynamicSharedMemorySize, l0) !=

@@ -44,12 +44,16 @@ __device__ __forceinline__ void split_pair(float v0, float v1, h2 &hi, h2 &lo) {
     hi = __builtin_bit_cast(h2, h);
 #if BALF_SPLIT_MIX
     // lo = f16(v - hi) straight from the packed halves: v_fma_mix{lo,hi}_f16 read hi as f16, v as f32, and write
-    // one half of the destination each -- 3 instructions per pair instead of the 5 hipcc emits for the casts
+    // one half of the destination each -- 3 instructions per pair instead of the 5 hipcc emits for the casts.
+    // The result is built IN v0's REGISTER ("+v"): hipcc does not pad hazards around inline asm, and a free register
+    // picked for a separate output can be the SrcC (bias) of an MFMA issued a few cycles earlier -- a VALU write within
+    // 7 wait states of such an MFMA corrupts its accumulator input (measured: non-deterministic 1e-4 errors).  v0's
+    // register holds a live VALU result up to this point, so no MFMA in flight can be reading it.
     const unsigned hu = __builtin_bit_cast(unsigned, h);
-    unsigned lu;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "=&v"(lu) : "v"(hu), "v"(v0), "v"(v1));
+    unsigned lu = __builtin_bit_cast(unsigned, v0);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "+v"(lu) : "v"(hu), "v"(v1));
     lo = __builtin_bit_cast(h2, lu);
 #else
     const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(fmaf((float)hi[0], -1.0f, v0), fmaf((float)hi[1], -1.0f, v1));

@@ -38,7 +38,13 @@ template <int MODE> constexpr int s1_weight_bytes() { return MODE == 0 ? kS1Q2 :
 enum S1Par { kS1pConv0B = 0, kS1pQ1B = 32, kS1pD1B = 64, kS1pGlnG = 128, kS1pGlnB = 160, kS1pMixB1 = 192, kS1pD2B = 256,
              kS1pQ2B = 288, kS1pR1B = 320, kS1pR2B = 352, kS1pLut = 384, kS1ParFloats = 640 };
 // ... then one transposed token tile per wave.
-template <int MODE> constexpr int s1_waves() { return MODE == 0 ? 12 : 8; }      // 3 / 2 waves per SIMD
+#ifndef BALF_S1_NW0
+#define BALF_S1_NW0 12
+#endif
+#ifndef BALF_S1_NW1
+#define BALF_S1_NW1 8
+#endif
+template <int MODE> constexpr int s1_waves() { return MODE == 0 ? BALF_S1_NW0 : BALF_S1_NW1; }   // 3 / 2 waves per SIMD
 template <int MODE> constexpr int s1_lds_bytes() {
     return s1_weight_bytes<MODE>() + kS1ParFloats * 4 + s1_waves<MODE>() * kS1BtBytes;
 }
@@ -148,9 +154,38 @@ __device__ __forceinline__ float row_ror_add(float v) {
     return v + __builtin_bit_cast(float, r);
 }
 
-template <int MODE>
+// Vector-memory discipline of the float-input kernels (U8 = false).  vmcnt counts loads and stores together, in issue
+// order, and the compiler drains it to zero at the loop's back edge as soon as it has a load of its own pending -- which
+// makes every group wait for the previous group's 8-16 KiB of stores (measured: 40 % of the grid kernel's time).  So every
+// LOAD of the loop is inline asm with a counted wait placed by hand (the compiler, seeing only stores, never waits):
+//   top of group i:   wait for the input pixels of group i       (younger operations: the stores of group i-1 -> vmcnt(8))
+//                     issue the u' rows of group i (block branch), then the input pixels of group i+1
+//   before RSHMAG.dense2 (block): wait for the u' rows          (younger: the 3 input loads -> vmcnt(3))
+// The loads of the last group's successor are issued anyway (clamped to a valid group) so that the counts are static.
+// a wave-uniform pointer as a scalar-register pair (hipcc does 64-bit multiplies of uniform values on the vector unit
+// and then hands the asm's "s" operand a VGPR pair)
+template <typename T>
+__device__ __forceinline__ const T *uniform_ptr(const T *p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<const T *>(((unsigned long long)hi << 32) | lo);
+}
+
+#ifndef BALF_S1_STRICT
+#define BALF_S1_STRICT 0     // 1: every hand-placed wait drains the queue (debugging aid)
+#endif
+#if BALF_S1_STRICT
+#define BALF_S1_WAIT_IN "s_waitcnt vmcnt(0)"
+#define BALF_S1_WAIT_U "s_waitcnt vmcnt(0)"
+#else
+#define BALF_S1_WAIT_IN "s_waitcnt vmcnt(8)"
+#define BALF_S1_WAIT_U "s_waitcnt vmcnt(3)"
+#endif
+template <int MODE, bool U8>
 __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(StageArgs A) {
     constexpr int C = kS1C, P = 4, NW = s1_waves<MODE>(), NTHR = NW * 64;
+    constexpr int STAMP_KID = MODE; (void)STAMP_KID;
+    STAMP_DECL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *par = reinterpret_cast<float *>(smem_raw + s1_weight_bytes<MODE>());
     const int lane = threadIdx.x & 63, q = lane >> 4, li = lane & 15;
@@ -227,54 +262,125 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     const int nx = (gridDim.x >> 3) * NW;                        // waves per XCD (gridDim.x is a multiple of 8)
     const int wx = (blockIdx.x >> 3) * NW + wave, xcd = blockIdx.x & 7;
 
-    for (int round = 0;; ++round) {
-        const int item = (round * 8 + xcd) * nx + wx;            // wave-uniform
-        if (item >= total) break;
-        const int n = item / per_img, rem = item - n * per_img;
-        const int gy = rem / fw, gx = rem - gy * fw;             // block (by, bx) or in-cell offset (iy, ix)
-        const int ty = li >> 1, tx0 = 4 * (li & 1);
-        long pix0;                                               // pixel of tile 0; tile p is pix0 + p * pstep
-        int y, x0, pstep;
-        if (MODE == 0) { y = ty * fh + gy; x0 = tx0 * fw + gx; pstep = fw; }
-        else           { y = 8 * gy + ty;  x0 = 8 * gx + tx0;  pstep = 1; }
-        pix0 = ((long)n * H + y) * W + x0;
-
-        // ---- network input of the lane's four pixels as the B fragments of conv0 (k-slots: q = 0, j = 0..2) ----
-        HL bx[P];
-        {
-            float in[P][3];
-            if (q == 0) {
-                if (A.u8_ch == 0) {
-                    const long hw = (long)H * W;
-                    const float *xp = A.X + (long)n * 3 * hw + (long)y * W + x0;
-                    if (MODE == 1) {                             // four adjacent pixels: 16-byte aligned
+    // group index -> (image n, gy, gx) [block (by, bx) or in-cell offset (iy, ix)], advanced incrementally by the
+    // schedule's stride (two integer divisions per group would cost ~80 scalar instructions each)
+    struct Pos { int n, gy, gx; };
+    struct Geo { int n, y, x0; long pix0; };
+    const int ty = li >> 1, tx0 = 4 * (li & 1);
+    const int pstep = (MODE == 0) ? fw : 1;
+    auto decompose = [&](int i) {
+        Pos c;
+        c.n = i / per_img;
+        const int rem = i - c.n * per_img;
+        c.gy = rem / fw;
+        c.gx = rem - c.gy * fw;
+        // (integer division runs on the vector unit: bring the wave-uniform results back to scalar registers, the asm
+        // loads below take their base addresses in SGPRs)
+        c.n = __builtin_amdgcn_readfirstlane(c.n);
+        c.gy = __builtin_amdgcn_readfirstlane(c.gy);
+        c.gx = __builtin_amdgcn_readfirstlane(c.gx);
+        return c;
+    };
+    auto geo = [&](const Pos &c) {
+        Geo g;
+        g.n = c.n;
+        if (MODE == 0) { g.y = ty * fh + c.gy; g.x0 = tx0 * fw + c.gx; }
+        else           { g.y = 8 * c.gy + ty;  g.x0 = 8 * c.gx + tx0; }
+        g.pix0 = ((long)g.n * H + g.y) * W + g.x0;
+        return g;
+    };
+    // raw network input of the lane's four pixels (lanes q = 0 only: k-slots q = 0, j = 0..2 of conv0's B operand):
+    // float bits, or (U8) the uint8 value, 0x100 = outside the image: zero padding
+    auto load_raw_u8 = [&](const Geo &g, unsigned (&raw)[P][3]) {
+        if (q != 0) return;
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const f4 v = ldg4(xp + k * hw);
+        for (int p = 0; p < P; ++p) {
+            const int yy = g.y - A.u8_top, xx = g.x0 + p * pstep - A.u8_left;
+            const bool ok = yy >= 0 && yy < A.u8_h && xx >= 0 && xx < A.u8_w;
+            const unsigned char *px8 = A.X8 + (((long)g.n * A.u8_h + (ok ? yy : 0)) * A.u8_w + (ok ? xx : 0)) * A.u8_ch;
 #pragma unroll
-                            for (int p = 0; p < P; ++p) in[p][k] = v[p];
-                        }
-                    } else {
-#pragma unroll
-                        for (int p = 0; p < P; ++p)
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) in[p][k] = xp[k * hw + p * pstep];
-                    }
-                } else {
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        const int yy = y - A.u8_top, xx = x0 + p * pstep - A.u8_left;
-                        const bool ok = yy >= 0 && yy < A.u8_h && xx >= 0 && xx < A.u8_w;
-                        const unsigned char *px8 =
-                            A.X8 + (((long)n * A.u8_h + (ok ? yy : 0)) * A.u8_w + (ok ? xx : 0)) * A.u8_ch;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) in[p][k] = ok ? par[kS1pLut + px8[A.u8_ch == 3 ? k : 0]] : 0.0f;
-                    }
-                }
+            for (int k = 0; k < 3; ++k) raw[p][k] = ok ? (unsigned)px8[A.u8_ch == 3 ? k : 0] : 0x100u;
+        }
+    };
+    const int hw = H * W;                                       // (32-bit: keeps the plane offsets on the scalar unit)
+    // float input, asm loads (not counted by the compiler): plane k of image n at a scalar base, the lane's pixel offset
+    // in a VGPR.  Lanes q != 0 are masked off and keep the zeros `raw` starts with.
+    auto issue_raw = [&](const Geo &g, unsigned (&raw)[P][3], f4 (&rawv)[3]) {
+        const unsigned voff = (unsigned)(g.y * W + g.x0) * 4u;
+        const float *xb = A.X + (long)g.n * 3 * (long)hw;
+        const float *x0p = uniform_ptr(xb), *x1p = uniform_ptr(xb + hw), *x2p = uniform_ptr(xb + 2 * hw);
+        if (q == 0) {
+            if constexpr (MODE == 1) {
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %5\n\t"
+                             "global_load_dwordx4 %2, %3, %6"
+                             : "+v"(rawv[0]), "+v"(rawv[1]), "+v"(rawv[2]) : "v"(voff), "s"(x0p), "s"(x1p), "s"(x2p) : "memory");
             } else {
 #pragma unroll
-                for (int p = 0; p < P; ++p) in[p][0] = in[p][1] = in[p][2] = 0.0f;
+                for (int p = 0; p < P; ++p) {
+                    const unsigned vp = voff + (unsigned)(p * pstep) * 4u;
+                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %3, %4\n\tglobal_load_dword %1, %3, %5\n\t"
+                                 "global_load_dword %2, %3, %6"
+                                 : "+v"(raw[p][0]), "+v"(raw[p][1]), "+v"(raw[p][2]) : "v"(vp), "s"(x0p), "s"(x1p), "s"(x2p) : "memory");
+                }
             }
+        }
+    };
+    const int stride = 8 * nx;
+    const Pos step = decompose(stride);
+    auto advance = [&](Pos c) {
+        c.gx += step.gx;
+        if (c.gx >= fw) { c.gx -= fw; ++c.gy; }
+        c.gy += step.gy;
+        if (c.gy >= fh) { c.gy -= fh; ++c.n; }
+        c.n += step.n;
+        c.n = __builtin_amdgcn_readfirstlane(c.n);
+        c.gy = __builtin_amdgcn_readfirstlane(c.gy);
+        c.gx = __builtin_amdgcn_readfirstlane(c.gx);
+        return c;
+    };
+    int item = xcd * nx + wx;                                    // wave-uniform
+    Pos nxt = decompose(item);
+    unsigned raw[P][3] = {};
+    f4 rawv[3] = {};
+    if (!U8 && item < total) {
+        issue_raw(geo(nxt), raw, rawv);
+        // the first group has no older stores in front of its pixels: drain (the counted wait in the loop assumes them)
+        if constexpr (MODE == 1)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawv[0]), "+v"(rawv[1]), "+v"(rawv[2]) :: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[1][0]), "+v"(raw[1][1]),
+                           "+v"(raw[1][2]), "+v"(raw[2][0]), "+v"(raw[2][1]), "+v"(raw[2][2]), "+v"(raw[3][0]),
+                           "+v"(raw[3][1]), "+v"(raw[3][2]) :: "memory");
+    }
+
+    for (; item < total; item += stride) {
+        const Geo g = geo(nxt);
+        if (item + stride < total) nxt = advance(nxt);           // (the last group re-requests its own pixels)
+        const long pix0 = g.pix0;
+        if (U8) load_raw_u8(g, raw);
+        STAMP(0);
+        HL bx[P];                                                // conv0's B fragments
+        {
+            if constexpr (!U8) {
+                // the input pixels of this group have landed; the previous group's stores may still be in flight
+                if constexpr (MODE == 1)
+                    asm volatile(BALF_S1_WAIT_IN : "+v"(rawv[0]), "+v"(rawv[1]), "+v"(rawv[2]) :: "memory");
+                else
+                    asm volatile(BALF_S1_WAIT_IN
+                                 : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[1][0]), "+v"(raw[1][1]),
+                                   "+v"(raw[1][2]), "+v"(raw[2][0]), "+v"(raw[2][1]), "+v"(raw[2][2]), "+v"(raw[3][0]),
+                                   "+v"(raw[3][1]), "+v"(raw[3][2]) :: "memory");
+            }
+            float in[P][3];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (U8) in[p][k] = (q == 0 && raw[p][k] < 256u) ? par[kS1pLut + (raw[p][k] & 255u)] : 0.0f;
+                    else if (MODE == 1) in[p][k] = rawv[k][p];
+                    else in[p][k] = __builtin_bit_cast(float, raw[p][k]);
+                }
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 h2 h01, l01, h2x, l2x;
@@ -284,6 +390,23 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
                 bx[p].lo = h8{l01[0], l01[1], l2x[0], 0, 0, 0, 0, 0};
             }
         }
+        HL ub[(MODE == 1) ? P : 1];                              // block: u' rows of the lane's pixels (pre-split in HBM)
+        if constexpr (MODE == 1) {
+            if constexpr (U8) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) ub[p] = load_frag_px(A.U, pix0 + p * pstep, C, 0, q);
+            } else {
+                const unsigned uoff = (unsigned)(g.y * W + g.x0) * 128u + q * 16u;
+                const char *ubase = uniform_ptr(reinterpret_cast<const char *>(A.U) + (long)g.n * (long)hw * 128);
+#define BALF_S1_UB(PI)                                                                                              \
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 offset:%c4\n\tglobal_load_dwordx4 %1, %2, %3 offset:%c5"        \
+                 : "=&v"(ub[PI].hi), "=&v"(ub[PI].lo) : "v"(uoff), "s"(ubase), "i"(PI * 128), "i"(PI * 128 + 64) : "memory")
+                BALF_S1_UB(0); BALF_S1_UB(1); BALF_S1_UB(2); BALF_S1_UB(3);
+#undef BALF_S1_UB
+            }
+        }
+        if constexpr (!U8) issue_raw(geo(nxt), raw, rawv);       // next group's pixels (12 or 3 loads, always)
+        STAMP(1);   // input -> conv0 B fragments (waits for the prefetched pixels), next group's loads issued
         auto conv0 = [&](f4 (&x0v)[2][P]) {                      // x0 = relu(conv0(X)); bit-identical every time
             s1_bias(x0v, par + kS1pConv0B, q);
             s1_linear(x0v, wl + kS1Conv0, 2048, bx);
@@ -296,16 +419,20 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             conv0(x0v);
             s1_ln_split(x0v, b);
         }
+        STAMP(2);   // conv0 + relu + LN + split
         f4 z[2][P];                                              // u (grid) / v (block): kept for the branch residual
         s1_bias(z, par + kS1pQ1B, q);
         s1_linear(z, wl + kS1Q1, 2048, b);
         gelu<false>(z);
+        STAMP(3);   // dense1 half + GELU
         s1_ln_split(z, b);
+        STAMP(4);   // LN + split
 
         f4 ga[2][P];
         s1_bias(ga, par + kS1pD1B, q);
         s1_linear(ga, wl + kS1D1, 2048, b);
         gelu<false>(ga);
+        STAMP(5);   // branch dense1 (a half) + GELU
         {
             f4 gb[2][P];
             s1_bias(gb, par + kS1pD1B + C, q);
@@ -334,11 +461,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
                 }
             }
         }
-        HL ub[(MODE == 1) ? P : 1];                              // block: u' rows of the lane's pixels (pre-split), needed
-        if constexpr (MODE == 1) {                               // by RSHMAG.dense2 two Linears from here
-#pragma unroll
-            for (int p = 0; p < P; ++p) ub[p] = load_frag_px(A.U, pix0 + p * pstep, C, 0, q);
-        }
+        STAMP(6);   // branch dense1 (b half) + GELU + LN + transposed tile
         {
             // mix^T[c][g'] = sum_g bT[c][g] Wmix[g'][g] (+ bias[g'] + 1 as the accumulator's start value), then the gate
             HL a[2][2];
@@ -367,6 +490,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
                 }
             }
         }
+        STAMP(7);   // token mix + gate
         s1_split(ga, b);
         f4 o[2][P];
         s1_bias(o, par + kS1pD2B, q);
@@ -376,15 +500,22 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
 #pragma unroll
             for (int p = 0; p < P; ++p) o[nt][p] += z[nt][p];
 
+        STAMP(8);   // dense2 + residual
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int p = 0; p < P; ++p) store_frag_px(A.U, pix0 + p * pstep, C, 0, q, split8(o[0][p], o[1][p]));
+            STAMP(9);   // u' store
         } else {
             s1_split(o, b);
             f4 x1[2][P];
             s1_bias(x1, par + kS1pQ2B, q);
             s1_linear(x1, wl + kS1Q2 + 2048, 2 * 2048, b);       // K-step 1 = v' half of cat[u', v']
+            if constexpr (!U8)                                   // u' rows have landed (younger: next group's 3 input loads)
+                asm volatile(BALF_S1_WAIT_U
+                             : "+v"(ub[0].hi), "+v"(ub[0].lo), "+v"(ub[1].hi), "+v"(ub[1].lo), "+v"(ub[2].hi), "+v"(ub[2].lo),
+                               "+v"(ub[3].hi), "+v"(ub[3].lo) :: "memory");
             s1_linear(x1, wl + kS1Q2, 2 * 2048, ub);             // K-step 0 = u' half
+            STAMP(9);   // RSHMAG dense2 over cat[u', v'] (u' from HBM)
             {
                 f4 x0v[2][P];
                 conv0(x0v);                                      // recomputed (24 MFMAs) instead of kept (32 registers)
@@ -396,12 +527,14 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
                         *reinterpret_cast<f4 *>(A.R + (pix0 + p * pstep) * C + 16 * nt + 4 * q) = x1[nt][p] + x0v[nt][p];
                     }
             }
+            STAMP(10);  // conv0 again, residuals, R store
             s1_ln_split(x1, b);
             f4 m1[2][P];
             s1_bias(m1, par + kS1pR1B, q);
             s1_linear(m1, wl + kS1R1, 2048, b);
             lrelu(m1);
             s1_split(m1, b);
+            STAMP(11);  // LN + conv1 + lrelu + split
             f4 t[2][P];
             s1_bias(t, par + kS1pR2B, q);
             s1_linear(t, wl + kS1R2, 2048, b);
@@ -419,6 +552,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
                 for (int r = 0; r < 4; ++r) s[r] = row_ror_add<1>(row_ror_add<2>(row_ror_add<4>(row_ror_add<8>(s[r]))));
                 if (li == 0) *reinterpret_cast<f4 *>(A.partial + (long)item * C + 16 * nt + 4 * q) = s;
             }
+            STAMP(12);  // conv2 + T store + channel sums
         }
     }
 }

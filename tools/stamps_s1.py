@@ -1,0 +1,29 @@
+"""Per-phase cycle breakdown of the persistent stage-1 kernels (diagnostic build libbalf_hip_stamps.so, -DBALF_STAMPS=1):
+wave 0 of every workgroup stamps s_memtime between the phases of every token group it processes."""
+import ctypes as C, os, sys
+import torch
+sys.path.insert(0, ".")
+os.environ["BALF_HIP_LIB"] = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else "balf_amd/libbalf_hip_stamps.so")
+from balf_amd import arch
+from balf_amd.model import get_model
+from balf_amd.utils import synth
+m = get_model.load_model(arch.DEFAULT_MODEL_CFG); m.load_state_dict(synth.synthetic_state_dict(1)); m.precision = "fp16"
+m = m.eval().cuda()
+x = torch.rand((8, 3, 1088, 1920), device="cuda")
+raw = C.CDLL(os.environ["BALF_HIP_LIB"])
+sums = (C.c_ulonglong * (16 * 24))(); cnt = (C.c_ulonglong * 16)()
+m(x, want_logits=False); torch.cuda.synchronize()
+raw.balf_debug_stamps(sums, cnt, 1)
+for _ in range(2): m(x, want_logits=False)
+torch.cuda.synchronize()
+raw.balf_debug_stamps(sums, cnt, 0)
+names = {0: ["", "input", "conv0+LN", "q1+GELU", "LN+split", "d1a+GELU", "d1b+GELU+LN+bT", "mix+gate", "d2+res", "U store"],
+         1: ["", "input", "conv0+LN", "q1+GELU", "LN+split", "d1a+GELU", "d1b+GELU+LN+bT", "mix+gate", "d2+res", "q2(u',v')",
+             "conv0+R store", "LN+r1+lrelu", "r2+T store+sums"]}
+for kid in (0, 1):
+    n = cnt[kid]
+    if not n: continue
+    nm = names[kid]
+    tot = sum(sums[kid * 24 + i] for i in range(1, len(nm)))
+    print(f"stage1 {'block' if kid else 'grid'}: {n} groups stamped, {tot/n:8.0f} cycles/group:  " +
+          "  ".join(f"{nm[i]}={sums[kid*24+i]/n:.0f}" for i in range(1, len(nm))))
