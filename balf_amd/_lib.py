@@ -33,6 +33,7 @@ PROTOTYPES = {
     "balf_window_nms": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp]),
     "balf_nms_topk_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "balf_nms_topk": (_i, [_fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _fp, _vp, _vp, _sz, _vp]),
+    "balf_nms_threshold": (_i, [_fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp, _fp, _vp, _vp, _sz, _vp]),
     "balf_greedy_nms_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "balf_greedy_nms": (_i, [_fp, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _vp, _fp, _fp, _vp, _vp, _vp,
                             _sz, _vp]),
@@ -58,6 +59,7 @@ PROTOTYPES = {
     "balf_repeatability": (_i, [_vp, _i, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_double, _i, _vp, _vp, _vp, _vp,
                                _vp, _sz, _vp]),
     "balf_apply_homography": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "balf_common_region_masks": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "balf_profile_num_slots": (_i, []),
     "balf_profile_slot_name": (C.c_char_p, [_i]),
     "balf_profile_begin": (_i, []),
@@ -90,6 +92,23 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_checked_devices = set()
+
+
+def require_mi355x(device) -> None:
+    """Raise unless ``device`` is a gfx950 GPU (balf_device_check: the kernels are built for MI355X only).  Checked
+    once per device, by every op wrapper before its first launch there."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _checked_devices:
+        return
+    with torch.cuda.device(idx):
+        rc = lib().balf_device_check()
+    if rc != OK:
+        raise BalfHipError(f"cuda:{idx} is not an MI355X (gfx950): {lib().balf_error_string(rc).decode()} ({rc})")
+    _checked_devices.add(idx)
+
+
 def check(rc: int, what: str) -> None:
     if rc != OK:
         raise BalfHipError(f"{what} failed: {lib().balf_error_string(rc).decode()} ({rc})")
@@ -100,6 +119,7 @@ def require_gpu_tensor(t, name: str) -> None:
         raise BalfHipError(f"{name} must live on the GPU: balf_amd has no CPU path (got device {t.device})")
     if not t.is_contiguous():
         raise BalfHipError(f"{name} must be contiguous")
+    require_mi355x(t.device)
 
 
 def current_stream_ptr(device) -> int:

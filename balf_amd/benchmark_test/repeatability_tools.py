@@ -19,7 +19,10 @@ MAX_EDGES = 1 << 22
 def _device():
     if not torch.cuda.is_available():
         raise BalfHipError("balf_amd has no CPU path: compute_repeatability needs the GPU")
-    return torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    from .._lib import require_mi355x
+    require_mi355x(dev)
+    return dev
 
 
 def compute_repeatability(src_indexes, dst_indexes, overlap_err=0.4, eps=1e-6, dist_match_thresh=3, radious_size=30.):

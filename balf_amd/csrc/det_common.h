@@ -73,28 +73,29 @@ __device__ __forceinline__ float max0(float x) {
 #endif
 constexpr float kG0 = -1.000037633e+00f, kG1 = -1.150787766e+00f, kG2 = -4.599926517e-01f, kG3 = -5.182716455e-02f,
                 kG4 = 7.084460191e-03f, kG5 = -4.732939498e-04f;
+template <bool AS = (BALF_GELU_AS != 0)>
 __device__ __forceinline__ float gelu1(float x) {
     const float ax = fabsf(x);
-#if BALF_GELU_AS
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
-    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);     // coefficients pre-scaled by 1/2
-    p = fmaf(p, t, 0.5f * 1.421413741f);
-    p = fmaf(p, t, 0.5f * -0.284496736f);
-    p = fmaf(p, t, 0.5f * 0.254829592f);
-    const float y = p * t * e;                     // Phi(-|x|)
-    return fmaf(ax, 0.5f - y, 0.5f * x);           // = max(x, 0) - |x| y:  x >= 0: x(1 - y);  x < 0: x y
-#else
-    float p = fmaf(kG5, ax, kG4);
-    p = fmaf(p, ax, kG3);
-    p = fmaf(p, ax, kG2);
-    p = fmaf(p, ax, kG1);
-    p = fmaf(p, ax, kG0);
-    float e = __builtin_amdgcn_exp2f(p);
-    asm("" : "+v"(e));       // opaque: keeps hipcc from pairing two of these fmas into a v_pk_fma_f32, which has no
-                             // |x| modifier and costs two extra v_or_b32 per pair
-    return fmaf(-ax, e, max0(x));
-#endif
+    if constexpr (AS) {
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+        const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
+        float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);     // coefficients pre-scaled by 1/2
+        p = fmaf(p, t, 0.5f * 1.421413741f);
+        p = fmaf(p, t, 0.5f * -0.284496736f);
+        p = fmaf(p, t, 0.5f * 0.254829592f);
+        const float y = p * t * e;                     // Phi(-|x|)
+        return fmaf(ax, 0.5f - y, 0.5f * x);           // = max(x, 0) - |x| y:  x >= 0: x(1 - y);  x < 0: x y
+    } else {
+        float p = fmaf(kG5, ax, kG4);
+        p = fmaf(p, ax, kG3);
+        p = fmaf(p, ax, kG2);
+        p = fmaf(p, ax, kG1);
+        p = fmaf(p, ax, kG0);
+        float e = __builtin_amdgcn_exp2f(p);
+        asm("" : "+v"(e));       // opaque: keeps hipcc from pairing two of these fmas into a v_pk_fma_f32, which has no
+                                 // |x| modifier and costs two extra v_or_b32 per pair
+        return fmaf(-ax, e, max0(x));
+    }
 }
 
 // GELU on two values with the multiply/add work written as 2-wide vector math, which hipcc lowers to
@@ -131,7 +132,9 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
 #endif
 // PACKED: 2-wide vector math (v_pk_*): fewer VALU slots, but the register pairs it needs cost more than they
 // save in the register-starved kernels (block branch, C = 256) -- measured per kernel, see DESIGN.md.
-template <bool PACKED = true, int NT, int P>
+// AS: the longer Abramowitz-Stegun form -- kept for the 128-register N-split kernel of stage 3, which spills 35 registers
+// with the polynomial form (more evaluations in flight) and is latency-bound, not issue-bound.
+template <bool PACKED = true, bool AS = (BALF_GELU_AS != 0), int NT, int P>
 __device__ __forceinline__ void gelu(f4 (&t)[NT][P]) {
     if (BALF_ABLATE_GELU) return;                // timing experiment only
 #pragma unroll
@@ -143,7 +146,7 @@ __device__ __forceinline__ void gelu(f4 (&t)[NT][P]) {
                 t[nt][p] = f4{lo[0], lo[1], hi[0], hi[1]};
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[nt][p][r] = gelu1(t[nt][p][r]);
+                for (int r = 0; r < 4; ++r) t[nt][p][r] = gelu1<AS>(t[nt][p][r]);
             }
         }
 }

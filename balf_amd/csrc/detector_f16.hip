@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     f4 z[NTL][P];
     init_bias(z, par + kParQ1B * C + 16 * nt0, q);
     G(I1{}, z, from_slot);
-    gelu<false>(z);
+    gelu<false, (C == 128)>(z);
     {
         f4 h[NTL][P];
         ln_plain(z, h);
@@ -1145,12 +1145,12 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     f4 ga[NTL][P];
     init_bias(ga, par + kParD1B * C + 16 * nt0, q);
     G(I2{}, ga, from_slot);
-    gelu<false>(ga);
+    gelu<false, (C == 128)>(ga);
     {
         f4 gb[NTL][P];
         init_bias(gb, par + kParD1B * C + C + 16 * nt0, q);
         G(I3{}, gb, from_slot);
-        gelu<false>(gb);
+        gelu<false, (C == 128)>(gb);
         {
             float mean[P], rstd[P];
             ln_stats_ns<NTL, P>(gb, lnx, pg, hh, q, li, mean, rstd);

@@ -19,7 +19,8 @@
 #include "prof.h"
 
 int balf_topk_select_launch(const int2 *surv, const int *counts, long cap, int B, int K, int zero_fallback,
-                            int32_t *idx_dev, float *score_dev, int32_t *count_dev, hipStream_t st);
+                            int32_t *idx_dev, float *score_dev, int32_t *count_dev, hipStream_t st,
+                            unsigned thr_explicit);
 
 namespace {
 
@@ -283,7 +284,7 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
         return BALF_ERR_LAUNCH;
     // the K best kept points by score, sorted (score desc, index asc); count_dev = rows returned (<= K)
     int rc = balf_topk_select_launch(surv, counts, (long)H * W, B, K, /*zero_fallback=*/0, idx_dev, score_dev,
-                                     count_dev, st);
+                                     count_dev, st, /*thr_explicit=*/0u);
     if (rc != BALF_OK) return rc;
     if (subpixel_patch > 0) {
         hipLaunchKernelGGL(subpixel_kernel, dim3(balf_ceil_div(K, 256), B), dim3(256), 0, st, a, idx_dev, count_dev, K,

@@ -292,10 +292,13 @@ __device__ unsigned radix_select(int n, int rank, bool cached, const int2 (&ent)
     return prefix;
 }
 
+// thr_explicit = 0: the threshold is the K-th largest survivor score (find_index_higher_scores with threshold = -1,
+// test_utils.py:76-89).  thr_explicit != 0: the bits of a caller-given positive threshold (`threshold != -1`,
+// test_utils.py:91-95): every survivor with score >= it, the raster-first K of them if there are more.
 __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const int2 *surv_all, const int *surv_count,
                                                                   long cap, int K, int npow2, int zero_fallback,
-                                                                  int32_t *idx_out, float *score_out,
-                                                                  int32_t *count_out) {
+                                                                  unsigned thr_explicit, int32_t *idx_out,
+                                                                  float *score_out, int32_t *count_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);       // [npow2]
     unsigned *s_hist = reinterpret_cast<unsigned *>(keys + npow2);                 // [256]
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const int2 *su
     int32_t *idx_o = idx_out + (long)b * K;
     float *sc_o = score_out + (long)b * K;
 
-    if (n == 0 && !zero_fallback) {                       // greedy-NMS caller: no candidates, no points
+    if (n == 0 && (!zero_fallback || thr_explicit)) {     // greedy-NMS caller / explicit threshold: no candidates, no points
         for (int i = threadIdx.x; i < K; i += SEL_THREADS) { idx_o[i] = -1; sc_o[i] = 0.0f; }
         if (threadIdx.x == 0) count_out[b] = 0;
         return;
@@ -339,7 +342,31 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const int2 *su
 
     unsigned thr = 0;            // score bits; select score >= thr with idx <= idx_cut
     int idx_cut = 0x7fffffff;
-    if (n > K) {
+    if (thr_explicit) {
+        thr = thr_explicit;
+        if (threadIdx.x == 0) *s_cnt = 0;
+        __syncthreads();
+        int mine = 0;
+        if (cached) {
+#pragma unroll
+            for (int j = 0; j < CACHE; ++j)
+                if (threadIdx.x + j * SEL_THREADS < n && (unsigned)ent[j].y >= thr) ++mine;
+        } else {
+            for (int i = threadIdx.x; i < n; i += SEL_THREADS)
+                if ((unsigned)surv[i].y >= thr) ++mine;
+        }
+        if (mine) atomicAdd(s_cnt, mine);
+        __syncthreads();
+        const int reach = *s_cnt;
+        __syncthreads();
+        if (reach > K) {         // more than K pixels reach the threshold: `argwhere(...)[:K]` keeps the raster-first K
+            int d0, d1;
+            const unsigned t = thr;
+            idx_cut = (int)radix_select<false>(
+                n, K, cached, ent, surv, [t](int2 e, unsigned *k) { *k = (unsigned)e.x; return (unsigned)e.y >= t; },
+                s_hist, s_tmp, &d0, &d1);
+        }
+    } else if (n > K) {
         int n_eq, need_eq;
         thr = radix_select<true>(n, K, cached, ent, surv, [](int2 e, unsigned *k) { *k = (unsigned)e.y; return true; },
                                  s_hist, s_tmp, &n_eq, &need_eq);
@@ -422,7 +449,8 @@ int next_pow2(int v) {
 
 // shared by balf_nms_topk and balf_greedy_nms (nms_fast.hip)
 int balf_topk_select_launch(const int2 *surv, const int *counts, long cap, int B, int K, int zero_fallback,
-                            int32_t *idx_dev, float *score_dev, int32_t *count_dev, hipStream_t st) {
+                            int32_t *idx_dev, float *score_dev, int32_t *count_dev, hipStream_t st,
+                            unsigned thr_explicit) {
     const int npow2 = next_pow2(K);
     const size_t smem = (size_t)npow2 * 8 + 256 * 4 + 8 * 4;
     if (smem > 48 * 1024 &&
@@ -431,7 +459,7 @@ int balf_topk_select_launch(const int2 *surv, const int *counts, long cap, int B
         return BALF_ERR_LAUNCH;
     BALF_PROF(balf_prof::kTopkSelect, st,
               hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(SEL_THREADS), smem, st, surv, counts, cap, K, npow2,
-                                 zero_fallback, idx_dev, score_dev, count_dev));
+                                 zero_fallback, thr_explicit, idx_dev, score_dev, count_dev));
     BALF_LAUNCH_CHECK();
     return BALF_OK;
 }
@@ -452,9 +480,10 @@ extern "C" size_t balf_nms_topk_workspace_bytes(int B, int H, int W, int K) {
     return balf_align_up((size_t)B * sizeof(int), 256) + (size_t)B * (size_t)H * (size_t)W * sizeof(int2);
 }
 
-extern "C" int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W,
-                             int border, int nms_size, int K, int32_t *idx_dev, float *score_dev,
-                             int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+namespace {
+int nms_select(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W, int border,
+               int nms_size, int K, unsigned thr_explicit, int32_t *idx_dev, float *score_dev, int32_t *count_dev,
+               void *workspace_dev, size_t workspace_bytes, void *stream) {
     if (!prob_dev || !idx_dev || !score_dev || !count_dev || !workspace_dev) return BALF_ERR_ARG;
     if (B <= 0 || H <= 0 || W <= 0 || K <= 0 || border < 0) return BALF_ERR_ARG;
     if (nms_size < 1 || nms_size > BALF_MAX_NMS_SIZE || K > BALF_MAX_TOPK) return BALF_ERR_ARG;
@@ -472,7 +501,23 @@ extern "C" int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int c
     int rc = launch_nms_tiles(a, B, st);
     if (rc != BALF_OK) return rc;
 
-    rc = balf_topk_select_launch(surv, counts, (long)H * W, B, K, /*zero_fallback=*/1, idx_dev, score_dev, count_dev, st);
-    if (rc != BALF_OK) return rc;
-    return BALF_OK;
+    return balf_topk_select_launch(surv, counts, (long)H * W, B, K, /*zero_fallback=*/1, idx_dev, score_dev, count_dev, st,
+                                   thr_explicit);
+}
+}  // namespace
+
+extern "C" int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W,
+                             int border, int nms_size, int K, int32_t *idx_dev, float *score_dev,
+                             int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    return nms_select(prob_dev, B, Hp, Wp, crop_y, crop_x, H, W, border, nms_size, K, 0u, idx_dev, score_dev, count_dev,
+                      workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int balf_nms_threshold(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W,
+                                  int border, int nms_size, float threshold, int K, int32_t *idx_dev, float *score_dev,
+                                  int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    if (!(threshold > 0.0f) || !(threshold < INFINITY)) return BALF_ERR_ARG;   // <= 0 selects every pixel: host-side
+    const unsigned bits = __builtin_bit_cast(unsigned, threshold);
+    return nms_select(prob_dev, B, Hp, Wp, crop_y, crop_x, H, W, border, nms_size, K, bits, idx_dev, score_dev, count_dev,
+                      workspace_dev, workspace_bytes, stream);
 }

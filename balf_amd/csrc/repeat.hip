@@ -270,3 +270,86 @@ extern "C" int balf_apply_homography(const double *points_dev, int n, const doub
     BALF_LAUNCH_CHECK();
     return BALF_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// create_common_region_masks (/root/reference/balf/benchmark_test/geometry_tools.py:7-26): the part of each image that
+// the other image covers.  The reference warps an all-ones image whose 15-pixel frame is zeroed with
+// cv2.warpPerspective (default flags: bilinear, constant-zero border), thresholds at 0.75 and zeroes the frame of the
+// result.  Restated here from OpenCV's algorithm: the output pixel (x, y) samples the input at M^-1 (x, y, 1), the
+// source coordinates are rounded to 1/32 pixel (INTER_TAB_SIZE = 32, round half to even), the four bilinear weights
+// are the exact products of those 5-bit fractions.  cv2 is not installed in the build container: parity with it is
+// UNPINNED (checked against the oracle's restatement of the same algorithm only).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct MaskArgs {
+    double m[9];          // inverse map, row-major: output pixel -> input coordinates (homogeneous)
+    int h_out, w_out;     // mask being produced
+    int h_in, w_in;       // the all-ones image being warped
+    int border;
+    double *out;
+};
+
+__device__ __forceinline__ double ones_inner(int y, int x, int h, int w, int b) {
+    return (y >= b && y < h - b && x >= b && x < w - b) ? 1.0 : 0.0;      // zero outside the image too
+}
+
+__global__ __launch_bounds__(256) void common_mask_kernel(MaskArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)a.h_out * a.w_out) return;
+    const int y = (int)(i / a.w_out), x = (int)(i - (long)y * a.w_out);
+    double v = 0.0;
+    if (y >= a.border && y < a.h_out - a.border && x >= a.border && x < a.w_out - a.border) {
+        const double X0 = a.m[0] * x + a.m[1] * y + a.m[2];
+        const double Y0 = a.m[3] * x + a.m[4] * y + a.m[5];
+        double W = a.m[6] * x + a.m[7] * y + a.m[8];
+        W = W != 0.0 ? 32.0 / W : 0.0;
+        const double fx = fmax(-2147483648.0, fmin(2147483647.0, X0 * W));
+        const double fy = fmax(-2147483648.0, fmin(2147483647.0, Y0 * W));
+        const long long X = llrint(fx), Y = llrint(fy);                     // round half to even, like cvRound
+        const int sx = (int)(X >> 5), sy = (int)(Y >> 5);
+        const double ax = (double)(X & 31) * (1.0 / 32.0), ay = (double)(Y & 31) * (1.0 / 32.0);
+        const double s = ones_inner(sy, sx, a.h_in, a.w_in, a.border) * ((1.0 - ax) * (1.0 - ay)) +
+                         ones_inner(sy, sx + 1, a.h_in, a.w_in, a.border) * (ax * (1.0 - ay)) +
+                         ones_inner(sy + 1, sx, a.h_in, a.w_in, a.border) * ((1.0 - ax) * ay) +
+                         ones_inner(sy + 1, sx + 1, a.h_in, a.w_in, a.border) * (ax * ay);
+        v = s >= 0.75 ? 1.0 : 0.0;
+    }
+    a.out[i] = v;
+}
+
+bool invert3(const double *m, double *o) {
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C;
+    if (det == 0.0) return false;
+    const double r = 1.0 / det;
+    o[0] = A * r; o[1] = -(b * i - c * h) * r; o[2] = (b * f - c * e) * r;
+    o[3] = B * r; o[4] = (a * i - c * g) * r;  o[5] = -(a * f - c * d) * r;
+    o[6] = C * r; o[7] = -(a * h - b * g) * r; o[8] = (a * e - b * d) * r;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int balf_common_region_masks(const double *h_dst_2_src_host, int h_src, int w_src, int h_dst, int w_dst,
+                                        int border, double *mask_src_dev, double *mask_dst_dev, void *stream) {
+    if (!h_dst_2_src_host || !mask_src_dev || !mask_dst_dev) return BALF_ERR_ARG;
+    if (h_src <= 0 || w_src <= 0 || h_dst <= 0 || w_dst <= 0 || border < 0) return BALF_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // mask_src = warp(ones_dst, M = h_dst_2_src): samples ones_dst at M^-1 (x, y, 1)
+    // mask_dst = warp(ones_src, M = inv(h_dst_2_src) / its [2,2]): samples ones_src at M^-1 = a multiple of h_dst_2_src
+    MaskArgs ms{}, md{};
+    double inv_h[9];
+    if (!invert3(h_dst_2_src_host, ms.m)) return BALF_ERR_ARG;
+    for (int k = 0; k < 9; ++k) inv_h[k] = ms.m[k] / ms.m[8];               // the matrix the reference hands to cv2 ...
+    if (!invert3(inv_h, md.m)) return BALF_ERR_ARG;                          // ... and cv2 inverts again
+    ms.h_out = h_src; ms.w_out = w_src; ms.h_in = h_dst; ms.w_in = w_dst; ms.border = border; ms.out = mask_src_dev;
+    md.h_out = h_dst; md.w_out = w_dst; md.h_in = h_src; md.w_in = w_src; md.border = border; md.out = mask_dst_dev;
+    common_mask_kernel<<<balf_ceil_div((long)h_src * w_src, 256), 256, 0, st>>>(ms);
+    BALF_LAUNCH_CHECK();
+    common_mask_kernel<<<balf_ceil_div((long)h_dst * w_dst, 256), 256, 0, st>>>(md);
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}

@@ -2,6 +2,14 @@
 //
 // A value v is carried as two halves, hi = f16(v) and lo = f16(v - hi); a product is accumulated in fp32 as
 // hi*hi' + lo*hi' + hi*lo' (three v_mfma_f32_16x16x32_f16), ~2^-20 relative operand error.
+//
+// OPERAND RANGE.  hi is converted round-toward-zero and saturates at 65504; once |v| exceeds ~1.3e5 the residual
+// v - hi no longer fits f16 either and lo becomes +-inf, which the three products turn into inf/NaN without any
+// trap.  Below 6.1e-5 the halves go subnormal and precision degrades gracefully (2^-24 absolute).  Operands that
+// pass through a LayerNorm are O(1); the un-normalised ones (stage inputs after max-pool, the gated a*(mix+1), the
+// RCAB hidden layer after leaky-relu, the head input, the weights themselves) scale with the checkpoint.  The host
+// side offers MLP_MA_DECODER.validate_fp16() to check a checkpoint against the fp32 path (tests/test_forward_gpu.py
+// exercises activations up to ~1e4 and the out-of-range failure).
 #pragma once
 #include "common.h"
 

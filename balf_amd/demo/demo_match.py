@@ -24,8 +24,8 @@ _MAX_POINTS = 16384
 
 def _detect_gpu(args, im: np.ndarray, detector, device) -> torch.Tensor:
     """[n,3] (x, y, 1) on the GPU, strongest first, at most args.num_features rows."""
-    if args.order_coord != "xysr":
-        raise NotImplementedError("the demo path is implemented for order_coord='xysr' (the reference default)")
+    if args.order_coord not in ("xysr", "yxsr"):
+        raise ValueError(args.order_coord)
     img = torch.as_tensor(np.ascontiguousarray(im), device=device)
     if img.dtype != torch.uint8:
         raise ValueError("expected a uint8 image, as load_im returns it")
@@ -43,6 +43,8 @@ def _detect_gpu(args, im: np.ndarray, detector, device) -> torch.Tensor:
     else:
         ii = idx[0, :n].long()
         pts = torch.stack([(ii % w).float(), (ii // w).float()], dim=1)
+    if args.order_coord == "yxsr":        # rows (y, x, 1): whatever consumes them downstream sees them swapped, as in
+        pts = pts.flip(1)                 # the reference (test_utils.py:121-124 feeding demo_match.py:57,62-70)
     return torch.cat([pts, torch.ones((n, 1), device=device)], dim=1)
 
 
@@ -51,21 +53,30 @@ def detect_and_describe_batch(args, images_u8: torch.Tensor, detector, descripto
     (gray ``[B,H,W]`` or RGB ``[B,H,W,3]`` with their gray versions in ``gray_u8``) -> (xy [B,K,2] keypoints,
     strongest first; descriptors [B,K,128]; count [B] valid rows per image), K = args.num_features.  Per image this
     is what :func:`extract_features` returns (demo_match.py:59-95)."""
-    if args.order_coord != "xysr":
-        raise NotImplementedError("the demo path is implemented for order_coord='xysr' (the reference default)")
+    if args.order_coord not in ("xysr", "yxsr"):
+        raise ValueError(args.order_coord)
     if gray_u8 is None:       # RGB without its gray version: PIL's convert('L') arithmetic on the GPU (demo_match.py:15-17)
         gray_u8 = images_u8 if images_u8.dim() == 3 else ops.rgb_to_gray_u8(images_u8.contiguous())
     b, h, w = images_u8.shape[:3]
     _, _, top, left = arch.padded_hw(h, w)
     k = min(int(args.num_features), h * w)
+    # The selection kernel keeps the raster-first K among the points that reach the K-th score (the window-max path's
+    # rule); the demo sorts by score and truncates (demo_match.py:54-55), so a point strictly above the K-th score must
+    # never lose to a tie at it: select as many as the kernel returns, truncate to num_features afterwards.
+    ksel = min(_MAX_POINTS, h * w)
     with torch.inference_mode():
         prob = detector.forward_u8(images_u8, want_logits=False)["prob"]
         idx, score, xy, count, total = ops.greedy_nms(prob, top, left, h, w, args.border_size,
-                                                      args.heatmap_confidence_threshold, args.nms_size, k,
+                                                      args.heatmap_confidence_threshold, args.nms_size, ksel,
                                                       args.patch_size if args.sub_pixel else 0)
+        idx, count = idx[:, :k].contiguous(), count.clamp(max=k)
         if not args.sub_pixel:
             ii = idx.long().clamp_(min=0)
             xy = torch.stack([(ii % w).float(), (ii // w).float()], dim=2)
+        else:
+            xy = xy[:, :k].contiguous()
+        if args.order_coord == "yxsr":
+            xy = xy.flip(2)
         patches = ops.extract_patches_batch(gray_u8, xy, count, float(args.s_mult))
         descs = descriptor.forward_slots(patches, count)          # unused slots: zero rows, no compute
     return xy, descs, count

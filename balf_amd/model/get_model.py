@@ -32,7 +32,7 @@ def _load_optimizer(optimizer, checkpoint, filename, loc):
     assert filename[-4] == '.', filename
     side = '%s_optim.%s' % (filename[:-4], filename[-3:])
     if os.path.exists(side):
-        optimizer.load_state_dict(torch.load(side, map_location=loc, weights_only=False)['optimizer_state'])
+        optimizer.load_state_dict(torch.load(side, map_location=loc)['optimizer_state'])     # get_model.py:44,80
 
 
 def load_test_pretrained_model(model, filename, optimizer=None, device='cuda'):
@@ -54,7 +54,7 @@ def load_pretrained_model(model, filename, logger, optimizer=None, device='cuda'
         raise FileNotFoundError
     logger.info('==> Loading parameters from checkpoint %s to %s' % (filename, 'CPU' if device == 'cpu' else 'GPU'))
     loc = torch.device('cpu') if device == 'cpu' else None
-    checkpoint = torch.load(filename, map_location=loc, weights_only=False)
+    checkpoint = torch.load(filename, map_location=loc)      # torch's default unpickling policy, as get_model.py:14-15
     update, own = _load_into(model, checkpoint, lambda msg, updated: logger.info(msg))
     _load_optimizer(optimizer, checkpoint, filename, loc)
     assert len(update) == len(own)

@@ -64,7 +64,7 @@ def _down(cin, c, a):
 
 
 class MLP_MA_DECODER(nn.Module):
-    def __init__(self, model_cfg, precision: str = "fp32"):
+    def __init__(self, model_cfg, precision: str = "fp16"):
         super().__init__()
         a = {k: model_cfg[k] for k in ("en_embed_dims", "grid_size", "block_size", "grid_gmlp_factor",
                                        "block_gmlp_factor", "input_proj_factor", "channels_reduction",
@@ -78,6 +78,7 @@ class MLP_MA_DECODER(nn.Module):
         head.norm = nn.BatchNorm2d(a["cell_size"] ** 2 + 1)
         self.detector_head = head
         self.precision = precision
+        self._tensors = None           # (module, attribute) of every state tensor, see _state_tensors
         self._packed = None            # (device blob, key) cache; rebuilt when parameters change
         self._packed_key = None
 
@@ -88,9 +89,16 @@ class MLP_MA_DECODER(nn.Module):
         except KeyError:
             raise ValueError(f"precision must be 'fp32' or 'fp16', got {self.precision!r}")
 
+    def _state_tensors(self):
+        """The 167 state tensors in state_dict order, collected once (module structure is fixed after __init__);
+        ``load_state_dict`` / ``.to()`` / in-place updates change data pointers or versions, which the key tracks."""
+        if self._tensors is None:
+            self._tensors = [(m, n) for m in self.modules() for n in
+                             list(m._parameters.keys()) + [b for b in m._buffers.keys() if b not in m._non_persistent_buffers_set]]
+        return [getattr(m, n) for m, n in self._tensors]
+
     def _state_key(self, device):
-        return (str(device), self.precision,
-                tuple(_lib.tensor_key(t) for t in self.state_dict().values()))
+        return (str(device), self.precision, tuple(_lib.tensor_key(t) for t in self._state_tensors()))
 
     def packed_weights(self, device) -> torch.Tensor:
         key = self._state_key(device)
@@ -130,6 +138,7 @@ class MLP_MA_DECODER(nn.Module):
             raise ValueError(f"H and W must be multiples of 64 (pad with mod_padding_symmetric), got {h}x{w}")
         x = x.contiguous().float()
         dev = x.device
+        _lib.require_mi355x(dev)
         l = lib()
         blob = self.packed_weights(dev)
         prob = torch.empty((b, h, w), dtype=torch.float32, device=dev)
@@ -141,6 +150,28 @@ class MLP_MA_DECODER(nn.Module):
                                  logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
                                  ws.numel(), _lib.current_stream_ptr(dev)), "balf_forward")
         return {"logits": logits, "prob": prob}
+
+    def validate_fp16(self, x: torch.Tensor, tol: float = 1e-4) -> float:
+        """Check the split-f16 path against the exact-fp32 path on ``x`` (a padded [B,3,H,W] batch): returns the
+        max-abs score-map difference and raises if it exceeds ``tol`` or if the f16 path produced a non-finite value.
+        Worth one call per new checkpoint: every MFMA operand is carried as two f16 halves, so an activation or
+        weight beyond +-6.5e4 saturates (split16.h) -- LayerNorm keeps most operands O(1), but the stage inputs, the
+        gated branch, the RCAB hidden layer and the head input scale with the checkpoint's weights."""
+        keep = self.precision
+        try:
+            self.precision = "fp32"
+            ref = self.forward(x, want_logits=False)["prob"]
+            self.precision = "fp16"
+            out = self.forward(x, want_logits=False)["prob"]
+        finally:
+            self.precision = keep
+        if not bool(torch.isfinite(out).all()):
+            raise BalfHipError("the split-f16 path produced non-finite values on this input: an operand left the f16 "
+                               "range (|v| < 6.5e4); use precision='fp32' for this checkpoint")
+        err = float((out - ref).abs().max())
+        if err > tol:
+            raise BalfHipError(f"split-f16 and fp32 score maps differ by {err:.3e} (> {tol:g}) on this input")
+        return err
 
     def forward_u8(self, images: torch.Tensor, want_logits: bool = True):
         """Raw uint8 images on the GPU -- gray ``[B,H,W]`` or RGB ``[B,H,W,3]`` -- straight into the network:
@@ -158,6 +189,7 @@ class MLP_MA_DECODER(nn.Module):
         ch = 1 if images.dim() == 3 else 3
         hp, wp, _, _ = arch.padded_hw(h, w)
         dev = images.device
+        _lib.require_mi355x(dev)
         l = lib()
         blob = self.packed_weights(dev)
         prob = torch.empty((b, hp, wp), dtype=torch.float32, device=dev)

@@ -10,15 +10,20 @@ import torch
 from . import _lib
 from ._lib import BalfHipError, check, current_stream_ptr, lib, require_gpu_tensor
 
-_workspaces: Dict[Tuple[str, int], torch.Tensor] = {}
+_workspaces: Dict[Tuple[str, int, int], torch.Tensor] = {}
 
 
 def _workspace(tag: str, device, nbytes: int) -> torch.Tensor:
-    """Caller-owned scratch, cached per device and grown on demand (the library never allocates)."""
-    key = (tag, device.index if device.index is not None else torch.cuda.current_device())
+    """Caller-owned scratch (the library never allocates), cached per (purpose, device, STREAM) and grown on demand.
+    Kernels of one stream run in order, so one buffer per stream is race-free; two streams (or two models driven from
+    two streams) get two buffers.  A buffer that is replaced by a larger one stays referenced by the caching allocator's
+    stream ordering: it was allocated and last used on this very stream."""
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (tag, dev_index, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 
@@ -42,10 +47,11 @@ def window_nms(score: torch.Tensor, border: int, nms_size: int) -> torch.Tensor:
 
 
 def nms_topk(prob: torch.Tensor, crop_y: int, crop_x: int, h: int, w: int, border: int, nms_size: int,
-             k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+             k: int, threshold: float = -1.0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """[B,Hp,Wp] fp32 score maps -> (idx [B,K] int32, score [B,K] fp32, count [B] int32); see
     balf_nms_topk in include/balf_hip.h.  ``k > h*w`` raises IndexError like the reference
-    (/root/reference/balf/utils/test_utils.py:83)."""
+    (/root/reference/balf/utils/test_utils.py:83).  ``threshold > 0`` selects by that value instead of the K-th
+    largest score (balf_nms_threshold; ``threshold != -1`` of find_index_higher_scores, test_utils.py:91-95)."""
     require_gpu_tensor(prob, "prob")
     if prob.dtype != torch.float32 or prob.dim() != 3:
         raise BalfHipError("prob must be a [B,Hp,Wp] float32 tensor")
@@ -59,10 +65,16 @@ def nms_topk(prob: torch.Tensor, crop_y: int, crop_x: int, h: int, w: int, borde
     nbytes = lib().balf_nms_topk_workspace_bytes(b, h, w, k)
     ws = _workspace("nms", dev, nbytes)
     with torch.cuda.device(dev):
-        check(lib().balf_nms_topk(prob.data_ptr(), b, hp, wp, int(crop_y), int(crop_x), int(h), int(w),
-                                  int(border), int(nms_size), int(k), idx.data_ptr(), score.data_ptr(),
-                                  count.data_ptr(), ws.data_ptr(), ws.numel(), current_stream_ptr(dev)),
-              "balf_nms_topk")
+        if threshold == -1:
+            check(lib().balf_nms_topk(prob.data_ptr(), b, hp, wp, int(crop_y), int(crop_x), int(h), int(w),
+                                      int(border), int(nms_size), int(k), idx.data_ptr(), score.data_ptr(),
+                                      count.data_ptr(), ws.data_ptr(), ws.numel(), current_stream_ptr(dev)),
+                  "balf_nms_topk")
+        else:
+            check(lib().balf_nms_threshold(prob.data_ptr(), b, hp, wp, int(crop_y), int(crop_x), int(h), int(w),
+                                           int(border), int(nms_size), float(threshold), int(k), idx.data_ptr(),
+                                           score.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           current_stream_ptr(dev)), "balf_nms_threshold")
     return idx, score, count
 
 

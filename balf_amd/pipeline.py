@@ -74,11 +74,15 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def allgather_keypoints(idx: torch.Tensor, score: torch.Tensor, count: torch.Tensor, group=None):
+def allgather_keypoints(idx: torch.Tensor, score: torch.Tensor, count: torch.Tensor, group=None, force: bool = False):
     """Every rank ends up with the keypoints of the whole batch, in rank order.  Slabs have the same
-    shape on every rank (equal shards; pad with ``-1`` rows otherwise)."""
+    shape on every rank (equal shards; pad with ``-1`` rows otherwise).  A single-rank group returns its
+    inputs untouched unless ``force`` is set (then the collective runs anyway: the plumbing check of
+    SURVEY.md 8e on a one-GPU box)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return idx, score, count
+    if dist.get_world_size(group) == 1 and not force:
         return idx, score, count
     world = dist.get_world_size(group)
     b, k = idx.shape

@@ -45,7 +45,10 @@ def remove_borders(image, borders):
 def _device():
     if not torch.cuda.is_available():
         raise BalfHipError("no GPU visible: balf_amd.utils.test_utils has no CPU fallback")
-    return torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    from .._lib import require_mi355x
+    require_mi355x(dev)
+    return dev
 
 
 def _as_map(score_map) -> np.ndarray:
@@ -63,14 +66,19 @@ def apply_nms(score_map, size):
 
 def find_index_higher_scores(map, num_points=1000, threshold=-1):
     """[row, col] pairs, in raster order, of the first ``num_points`` pixels whose value reaches the
-    ``num_points``-th largest value of the map (with the reference's <= 0 fallback)."""
-    if threshold != -1:
-        raise NotImplementedError("explicit thresholds are not on the accelerated path (threshold=-1 only)")
+    ``num_points``-th largest value of the map (with the reference's <= 0 fallback), or -- ``threshold != -1`` --
+    the given threshold (/root/reference/balf/utils/test_utils.py:74-95)."""
     m = _as_map(map)
     h, w = m.shape
+    if threshold != -1 and not threshold > 0:
+        # `map >= threshold` holds everywhere on a non-negative score map: the first num_points raster pixels
+        # (test_utils.py:91-95); index arithmetic only, nothing to compute
+        flat = np.flatnonzero(m.ravel() >= threshold)[: int(num_points)]
+        return np.stack([flat // w, flat % w], axis=1)
     t = torch.from_numpy(m).to(_device()).unsqueeze(0)
-    # a 1x1 window keeps every pixel, so this is the K-th-threshold selection alone
-    idx, _, cnt = ops.nms_topk(t, 0, 0, h, w, 0, 1, int(num_points))
+    # a 1x1 window keeps every pixel, so this is the threshold selection alone (K-th largest value, or the given one)
+    idx, _, cnt = ops.nms_topk(t, 0, 0, h, w, 0, 1, min(int(num_points), h * w) if threshold != -1 else int(num_points),
+                               threshold=float(threshold))
     flat = np.sort(idx[0, : int(cnt[0])].cpu().numpy().astype(np.int64))
     return np.stack([flat // w, flat % w], axis=1)
 

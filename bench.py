@@ -2,23 +2,27 @@
 """Benchmark of the BALF keypoint-detection hot path on MI355X.
 
 One step = one pass of the hot path (detector forward -> score map -> crop/border/window-max NMS ->
-exact top-K -> all-gather of keypoint slabs when N > 1) over one per-GPU batch of synthetic 1080p
-grayscale images already resident in HBM (gray replicated to 3 channels, /255, padded to 1088x1920:
-SURVEY.md F4/F5).  Workload = BASELINE.json configs[3] divided over the node: 32 images per GPU
-(256 over 8 GPUs), top-2000, border 15, nms 15; weak scaling.
+exact top-K -> all-gather of keypoint slabs) over one per-GPU batch of synthetic 1080p grayscale images
+already resident in HBM (gray replicated to 3 channels, /255, padded to 1088x1920: SURVEY.md F4/F5).
+Workload = BASELINE.json configs[3] divided over the node: 32 images per GPU (256 over 8 GPUs), top-2000,
+border 15, nms 15; weak scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp16|fp32]
-
---precision fp16 (default) = f16 MFMA with split (hi+lo) operands, three products per tile, fp32
-accumulate/LayerNorm/GELU/softmax/NMS: score map within 5e-6 of the reference (north-star bar 1e-4).
---precision fp32 = exact fp32 MFMA.  The other precision is also run (untimed headline, timed on its own)
-and reported under "other_precision".
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+--precision fp16 (default, and the module default) = f16 MFMA with split (hi+lo) operands, three products per
+MAC, fp32 accumulate/LayerNorm/GELU/softmax/NMS: score map within 1e-5 of the reference (north-star bar 1e-4).
+--precision fp32 = exact fp32 MFMA.  The other precision is timed too and reported under "other_precision".
+
 Rank 0 prints ONE JSON line.  `value` = images/s over all GPUs; `keypoints_per_s` rides along.
-`roofline` is for the dominant kernel (per-kernel device time from hipEvent pairs on the launch
-stream over the timed steps: balf_profile_begin/end in include/balf_hip.h); `cpu_baseline` times the
-CPU oracle (a port of the reference path, oracle/) on a bounded sample on rank 0 at N = 1.
+  roofline      the dominant kernel (per-kernel device time from hipEvent pairs on the launch stream over the timed
+                steps: balf_profile_begin/end in include/balf_hip.h) against the HBM roof (8 TB/s) and the dense f16 /
+                f32 MFMA peak of MI355X_MICROARCH.md; `traffic` = measured HBM bytes per launch and `issue` = the share
+                of the SIMDs' issue cycles its vector + matrix instructions need, both from the committed rocprofv3
+                --pmc passes of this script (profiles/r2_pmc.json); "bound" says which limit the kernel sits at.
+  index_match   BASELINE's "NMS index match vs CPU ref": the images of the CPU sample against the oracle.
+  cpu_baseline  the CPU oracle (a port of the reference path, oracle/) on a bounded sample, rank 0, N = 1.
+  other_configs the other BASELINE configurations that fit one GPU, a few steps each.
 """
 from __future__ import annotations
 
@@ -39,54 +43,41 @@ from balf_amd.model import get_model  # noqa: E402
 from balf_amd.utils import synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, dense f32 MFMA
-PEAK_FP16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA
+PEAK_FP16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA (the hardware's peak: the split path spends 3 products per MAC)
 PEAK_HBM_GBS = 8000.0
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r2_pmc.json")
+C_STAGE = [32, 64, 128, 256]
+CIN_STAGE = [3, 32, 64, 128]
 
 
 def stage_macs_per_pixel(s: int):
     """Algorithmic MACs per stage-resolution pixel of the two branch kernels:
     grid kernel = u half of dense1 + grid gMLP; block kernel = conv0 + v half + block gMLP + dense2 +
     RCAB convs.  Recomputed work (x0 and LN in the grid kernel) is not counted."""
-    c = [32, 64, 128, 256][s]
-    cin = [3, 32, 64, 128][s]
+    c, cin = C_STAGE[s], CIN_STAGE[s]
     grid = c * c + 2 * c * c + 64 * c + c * c
     block = cin * c + c * c + 2 * c * c + 64 * c + c * c + 2 * c * c + c * c + c * c
     return grid, block
 
 
-def kernel_bytes_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
-    """Algorithmic HBM bytes per launch of a branch kernel: what it must read and write once
-    (DESIGN.md 4.1 table): grid: stage input + u'; block: stage input + u' + t + r."""
-    if not (name.startswith("stage") and "branch" in name):
+def kernel_bytes_per_launch(name: str, mb: int, hp: int, wp: int, in_bytes_per_px: float = 12.0) -> float:
+    """Algorithmic HBM bytes per launch: what the kernel must read and write once.
+    grid: stage input + u'; block: stage input + u' + t + r; pool: t + r (4 pixels) + pooled output; head: t + r + prob."""
+    if not name.startswith("stage"):
         return 0.0
     s = int(name[5]) - 1
-    c = [32, 64, 128, 256][s]
-    cin = [3, 32, 64, 128][s]
+    c, cin = C_STAGE[s], CIN_STAGE[s]
     px = mb * (hp >> s) * (wp >> s)
-    per_px = 4.0 * (cin + c) if "grid" in name else 4.0 * (cin + c + 2 * c)
-    return per_px * px
-
-
-def measured_traffic(name: str, precision: str, mb: int, hp: int, wp: int):
-    """HBM bytes per launch of `name` from the committed PMC passes (profiles/r1_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this script at 8 images per launch, 1088x1920,
-    gfx950 corrections applied); None when the profile does not cover this shape."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    if not (os.path.isfile(path) and mb == 8 and (hp, wp) == (1088, 1920) and name.startswith("stage")):
-        return None
-    s = int(name[5]) - 1
-    c, cin = [32, 64, 128, 256][s], [3, 32, 64, 128][s]
-    suffix = "16" if precision == "fp16" else ""
-    if "branch" in name:
-        key = f"stage_branch_kernel{suffix}<{c}, {cin}, {0 if 'grid' in name else 1}>"
-    elif "pool" in name:
-        key = f"pool_kernel{suffix}<{c}>"
-    else:
-        return None
-    try:
-        return json.load(open(path))["kernels"][precision][key]["hbm_bytes_per_launch"]
-    except (KeyError, ValueError):
-        return None
+    x_in = in_bytes_per_px if s == 0 else 4.0 * cin
+    if "grid_branch" in name:
+        return (x_in + 4.0 * c) * px
+    if "block_branch" in name:
+        return (x_in + 4.0 * c + 8.0 * c) * px
+    if "pool" in name:
+        return (8.0 * c + 4.0 * c / 4.0) * px
+    if "head" in name:
+        return (8.0 * c + 64.0 * 4.0) * px
+    return 0.0
 
 
 def kernel_flops_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
@@ -100,18 +91,36 @@ def kernel_flops_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
     return 0.0
 
 
-def cpu_baseline(h, w, k, n_images, state, threads=0):
-    """The CPU oracle (port of the reference path) on `n_images` of the same workload.  The path is
-    layout/elementwise-bound on the CPU and slows down past a few dozen threads, so the
-    thread count is capped (256 threads measured 34 s/image on the GPU box, 8 threads 6.6 s in the build
-    container)."""
+def pmc_profile(precision: str, mb: int, hp: int, wp: int):
+    """The committed PMC passes (profiles/r2_pmc.json, tools/pmc_json.py): per profile slot, HBM bytes per launch and the
+    issue-slot accounting; None when they do not cover this shape."""
+    if not (os.path.isfile(PMC_PROFILE) and mb == 8 and (hp, wp) == (1088, 1920)):
+        return None
+    try:
+        return json.load(open(PMC_PROFILE))["slots"][precision]
+    except (KeyError, ValueError):
+        return None
+
+
+def synthetic_batch(h, w, lo, b):
+    """uint8 gray images lo .. lo+b-1 of the bench (alternating blur: smooth and noisy score maps)."""
+    return np.stack([synth.synthetic_gray_u8(h, w, lo + i, blur=5 if i % 2 == 0 else 1) for i in range(b)])
+
+
+def cpu_baseline(gray, k, state, threads=0):
+    """The CPU oracle (port of the reference path) on the images `gray` [n,H,W] uint8 of the same workload.  The path
+    is layout/elementwise-bound on the CPU and slows down past a few dozen threads, so the thread count
+    is capped (256 threads measured 34 s/image on the GPU box, 8 threads 6.6 s in the build container).
+    Returns (report, [padded score maps], [(idx raster order, score)])."""
     from oracle import oracle as O
     from oracle import c_oracle
     torch.set_num_threads(threads if threads > 0 else min(os.cpu_count() or 1, 32))
-    imgs = np.stack([synth.gray_to_rgb_norm(synth.synthetic_gray_u8(h, w, i)) for i in range(n_images)])
+    n_images, h, w = gray.shape
+    imgs = np.stack([synth.gray_to_rgb_norm(g) for g in gray])
     t0 = time.perf_counter()
     kp = 0
     t_fwd = t_nms = 0.0
+    probs, dets = [], []
     with torch.no_grad():
         for i in range(n_images):
             ta = time.perf_counter()
@@ -124,6 +133,8 @@ def cpu_baseline(h, w, k, n_images, state, threads=0):
             t_nms += time.perf_counter() - tb
             t_fwd += tb - ta
             kp += idx.size
+            probs.append(prob)
+            dets.append((idx, sc))
     dt = time.perf_counter() - t0
     cpu_model = ""
     try:
@@ -131,12 +142,36 @@ def cpu_baseline(h, w, k, n_images, state, threads=0):
             cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
     except OSError:
         pass
-    return {"value": n_images / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
-            "keypoints_per_s": kp / dt,
-            "forward_s_per_image": t_fwd / n_images, "nms_topk_s_per_image": t_nms / n_images,
-            "sample": f"{n_images} synthetic {w}x{h} gray images, batch 1, oracle forward (torch CPU fp32) + C NMS/top-{k}; "
-                      f"{dt:.1f} s"}
+    rep = {"value": n_images / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+           "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
+           "keypoints_per_s": kp / dt,
+           "forward_s_per_image": t_fwd / n_images, "nms_topk_s_per_image": t_nms / n_images,
+           "sample": f"{n_images} synthetic {w}x{h} gray images (the first of the GPU batch), batch 1, oracle forward "
+                     f"(torch CPU fp32) + C NMS/top-{k}; {dt:.1f} s"}
+    return rep, probs, dets
+
+
+def index_match(gpu, cpu_probs, cpu_dets, h, w, k, top, left):
+    """BASELINE's "NMS index match vs CPU ref" on the sampled images (reference pipeline:
+    /root/reference/balf/utils/train_utils.py:416-454).  `identical_input`: the C oracle's NMS/top-K on the very score
+    map the GPU produced gives the GPU's indices and score bits; `end_to_end_overlap`: GPU score map -> GPU NMS against
+    oracle score map -> oracle NMS (fraction of the K indices shared, worst image); `prob_max_abs_err`: the two score maps."""
+    from oracle import oracle as O
+    from oracle import c_oracle
+    idx, score, count, prob = gpu
+    ident, overlap, err = True, 1.0, 0.0
+    for i, (cp, (ci, _)) in enumerate(zip(cpu_probs, cpu_dets)):
+        gp = prob[i].cpu().numpy()
+        err = max(err, float(np.abs(gp - cp).max()))
+        ri, rs, _ = c_oracle.nms_topk(np.ascontiguousarray(gp[top:top + h, left:left + w]), 15, 15, k)
+        ri, rs = O.canonical_order(ri.astype(np.int64), rs)
+        n = int(count[i])
+        gi, gs = idx[i, :n].cpu().numpy(), score[i, :n].cpu().numpy()
+        ident = ident and n == ri.size and np.array_equal(gi, ri.astype(np.int32)) and \
+            np.array_equal(gs.view(np.uint32), rs.view(np.uint32))
+        overlap = min(overlap, len(set(gi.tolist()) & set(ci.tolist())) / float(max(1, ci.size)))
+    return {"images": len(cpu_probs), "identical_input": bool(ident), "end_to_end_overlap": overlap,
+            "prob_max_abs_err": err, "tolerance": 1e-4}
 
 
 def main():
@@ -146,13 +181,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="fp16", choices=["fp32", "fp16"])
     ap.add_argument("--other-steps", type=int, default=2, help="timed steps of the other precision (0 = skip)")
+    ap.add_argument("--other-configs", type=int, default=1, help="also time the other BASELINE configurations (N = 1)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cores, 32))")
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--topk", type=int, default=2000)
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-single-rank-collective", action="store_true",
+                    help="at N = 1 skip the single-rank RCCL group (then the step has no collective)")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON: libraries that print banners there (RCCL prints its version block when
+    # the first communicator comes up) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -161,11 +205,23 @@ def main():
         raise SystemExit("bench.py needs a GPU: balf_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    import torch.distributed as dist
+    collective_note = None
+    have_group = False
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        have_group = True
+    elif not args.no_single_rank_collective:
+        # one GPU: run the path's collective anyway on a single-rank RCCL group (SURVEY.md 8e caveat), so that the step
+        # timed here is the step the N > 1 runs time
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            have_group = True
+        except Exception as e:          # noqa: BLE001 -- report and go on without it
+            collective_note = f"none (single-rank RCCL group failed: {type(e).__name__}: {e})"[:200]
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
 
@@ -177,25 +233,34 @@ def main():
     model.precision = args.precision
     model = model.eval().to(dev)
 
-    # synthetic inputs, resident in HBM before the timed region: this rank's shard of the global batch
-    lo = rank * b
-    gray = np.stack([synth.synthetic_gray_u8(h, w, lo + i, blur=5 if i % 2 == 0 else 1) for i in range(b)])
-    g = torch.from_numpy(gray).to(dev).float().div_(255.0)
-    x = torch.zeros((b, 3, hp, wp), dtype=torch.float32, device=dev)
-    x[:, :, top:top + h, left:left + w] = g[:, None]
-    del g
+    def resident_input(gray_u8, hh, ww):
+        """padded fp32 NCHW batch in HBM, as the reference's callers hand it to the model"""
+        hp_, wp_, top_, left_ = arch.padded_hw(hh, ww)
+        g = torch.from_numpy(gray_u8).to(dev).float().div_(255.0)
+        x_ = torch.zeros((gray_u8.shape[0], 3, hp_, wp_), dtype=torch.float32, device=dev)
+        x_[:, :, top_:top_ + hh, left_:left_ + ww] = g[:, None]
+        return x_
 
-    def step():
-        idx, score, count, _ = pipeline.detect_batch(model, x, h, w, 15, 15, k, precomputed_offsets=(top, left))
-        return pipeline.allgather_keypoints(idx, score, count)
+    # synthetic inputs, resident in HBM before the timed region: this rank's shard of the global batch
+    gray = synthetic_batch(h, w, rank * b, b)
+    x = resident_input(gray, h, w)
+
+    def make_step(x_, hh, ww, kk):
+        _, _, top_, left_ = arch.padded_hw(hh, ww)
+
+        def step():
+            idx, score, count, prob = pipeline.detect_batch(model, x_, hh, ww, 15, 15, kk, precomputed_offsets=(top_, left_))
+            gi, gs, gc = pipeline.allgather_keypoints(idx, score, count, force=have_group)
+            return gi, gs, gc, (idx, score, count, prob)
+        return step
 
     def fence():
         torch.cuda.synchronize(dev)
-        if dist is not None:
+        if have_group:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    def timed_run(steps, warmup):
+    def timed_run(step, steps, warmup):
         for _ in range(warmup):
             o = step()
         fence()
@@ -206,7 +271,7 @@ def main():
         fence()
         dt_ = time.perf_counter() - t0
         prof_ = ops.profile_end()
-        if dist is not None:
+        if have_group and world > 1:
             tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_ = float(tmax.item())
@@ -215,46 +280,91 @@ def main():
     mb = max(1, min(b, 16 * 1024 * 1024 // (hp * wp)))          # images per launch (make_plan in det_common.h)
 
     def summarize(precision, dt_, prof_, steps):
-        """images/s + the roofline of the dominant kernel: whichever of the MFMA and HBM roofs it sits closer to."""
+        """images/s + the roofline of the dominant kernel against both roofs and the issue limit."""
         name, (ms, n_launch) = max(prof_.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / n_launch
         flops = kernel_flops_per_launch(name, mb, hp, wp)
         nbytes = kernel_bytes_per_launch(name, mb, hp, wp)
-        # f16 path: every algorithmic MAC costs three f16 MFMA products (hi*hi + lo*hi + hi*lo)
-        peak_tf = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_FP16_MFMA_TFLOPS / 3.0
+        peak_tf = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_FP16_MFMA_TFLOPS
         tf = flops / (avg_ms * 1e-3) / 1e12 if flops else 0.0
         gbs = nbytes / (avg_ms * 1e-3) / 1e9 if nbytes else 0.0
         f_m, f_h = tf / peak_tf, gbs / PEAK_HBM_GBS
+        pmc = pmc_profile(precision, mb, hp, wp)
+        slot = (pmc or {}).get(name)
         roof = {"kernel": name, "avg_launch_ms": avg_ms, "launches": n_launch, "images_per_launch": mb,
-                "traffic": measured_traffic(name, precision, mb, hp, wp),
+                "traffic": slot["hbm_bytes_per_launch"] if slot else None,
                 "mfma": {"achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": f_m,
-                         "algorithmic_flop_per_launch": flops},
+                         "algorithmic_flop_per_launch": flops,
+                         "products_per_mac": 3 if precision == "fp16" else 1},
                 "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h,
                         "algorithmic_bytes_per_launch": nbytes}}
-        if f_m >= f_h:
+        if slot:
+            # vector + matrix instructions of one launch priced at what a SIMD sustains (3.2 cycles per VALU instruction
+            # with >= 2 waves, 16 per 16x16x32 f16 MFMA / 32 per 16x16x4 f32 MFMA; tools/ubench/valu_issue.hip) over the
+            # SIMD cycles of the launch in the same profiled run
+            roof["issue"] = {k_: slot[k_] for k_ in ("valu_insts", "mfma_insts", "issue_share", "wave_wait_share",
+                                                     "wave_issue_stall_share", "waves") if k_ in slot}
+        share = (slot or {}).get("issue_share", 0.0)
+        if max(f_m, f_h) < 0.5 and share > max(f_m, f_h):
+            roof.update({"bound": "valu_issue", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h,
+                         "note": "neither roof above 0.5: vector/matrix instruction issue is the limit (see issue.issue_share); "
+                                 "achieved/peak/frac are the HBM figures"})
+        elif f_m >= f_h:
             roof.update({"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": f_m})
         else:
             roof.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h})
         fwd_ms = sum(v[0] for kname, v in prof_.items() if kname.startswith("stage")) / steps
         nms_ms = sum(v[0] for kname, v in prof_.items() if not kname.startswith("stage")) / steps
-        return {"images_per_s": world * b * steps / dt_, "ms_per_step": dt_ / steps * 1e3, "roofline": roof,
+        out_ = {"images_per_s": world * b * steps / dt_, "ms_per_step": dt_ / steps * 1e3, "roofline": roof,
                 "forward_device_ms_per_step": fwd_ms, "nms_topk_device_ms_per_step": nms_ms,
                 "forward_tflops": b * hp * wp * arch.FLOP_PER_PADDED_PIXEL / (fwd_ms * 1e-3) / 1e12,
                 "kernels_ms_per_step": {kname: v[0] / steps for kname, v in sorted(prof_.items())}}
+        if pmc:
+            tot = sum(v["hbm_bytes_per_launch"] for kname, v in pmc.items() if kname.startswith("stage"))
+            px = mb * hp * wp
+            out_["forward_hbm"] = {
+                "measured_bytes_per_launch_group": tot, "images": mb, "bytes_per_padded_pixel": tot / px,
+                "achieved_GBps": tot * (b / mb) / (fwd_ms * 1e-3) / 1e9,
+                "frac_of_8TBps": tot * (b / mb) / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "reference_points_bytes_per_px": {"algorithmic_minimum": 20.0, "fused_schedule_plan_fp16": 1100.0},
+                "source": "profiles/r2_pmc.json"}
+        return out_
 
-    dt, prof, out = timed_run(args.steps, args.warmup)
+    step = make_step(x, h, w, k)
+    dt, prof, out = timed_run(step, args.steps, args.warmup)
     counts = out[2]
     kp_per_image = float(counts.float().mean().item())
     head = summarize(args.precision, dt, prof, args.steps)
+    gpu_sample = tuple(t[:max(args.cpu_images, 1)].clone() for t in out[3])     # this rank's first images
 
     other = None
     other_prec = "fp32" if args.precision == "fp16" else "fp16"
     if args.other_steps > 0:
         model.precision = other_prec
-        dt2, prof2, _ = timed_run(args.other_steps, 1)
+        dt2, prof2, _ = timed_run(step, args.other_steps, 1)
         other = summarize(other_prec, dt2, prof2, args.other_steps)
         other["precision"] = other_prec
         model.precision = args.precision
+
+    # the other BASELINE configurations that fit one GPU (driver-timed too: a few steps each)
+    other_cfgs = None
+    if world == 1 and args.other_configs and (h, w, b) == (1080, 1920, 32):
+        other_cfgs = []
+        del x
+        for (name, bb, hh, ww, kk, prec, steps) in (("configs[1]: 32 x 640x480, top-1000", 32, 480, 640, 1000, "fp16", 5),
+                                                    ("configs[2]: 64 x 1280x720, top-2000, fp32", 64, 720, 1280, 2000, "fp32", 2),
+                                                    ("configs[2] on the split-f16 path", 64, 720, 1280, 2000, "fp16", 3),
+                                                    ("configs[4]: 128 x 1920x1080 fp16, top-2000 (1 GPU)", 128, 1080, 1920, 2000, "fp16", 2)):
+            model.precision = prec
+            xx = resident_input(synthetic_batch(hh, ww, 0, min(bb, 8)).repeat((bb + 7) // 8, axis=0)[:bb], hh, ww)
+            st = make_step(xx, hh, ww, kk)
+            d, _, o = timed_run(st, steps, 1)
+            other_cfgs.append({"workload": name, "precision": prec, "images_per_s": bb * steps / d,
+                               "keypoints_per_s": bb * steps / d * float(o[2].float().mean().item()),
+                               "ms_per_step": d / steps * 1e3, "steps": steps})
+            del xx, st, o
+        model.precision = args.precision
+        torch.cuda.empty_cache()
 
     if rank == 0:
         ips = head["images_per_s"]
@@ -262,8 +372,11 @@ def main():
         nms_ms = head["nms_topk_device_ms_per_step"]
         dtype = ("f16 MFMA, split hi+lo operands (3 products), f32 accumulate/LN/GELU/softmax/NMS"
                  if args.precision == "fp16" else "f32")
+        if collective_note is None:
+            collective_note = ("all_gather_into_tensor of [B,2K+1] int32 keypoint slabs (RCCL)"
+                               + ("" if world > 1 else ", single-rank group") if have_group else "none")
         res = {
-            "metric": "images/sec + keypoints/sec on 1080p gray (detector forward + NMS + top-K)",
+            "metric": "images/sec + keypoints/sec on 1080p gray (detector forward + NMS + top-K); NMS index match vs CPU ref",
             "value": ips, "unit": "images/s", "keypoints_per_s": ips * kp_per_image,
             "keypoints_per_image": kp_per_image,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
@@ -272,22 +385,29 @@ def main():
             "config": {"workload": f"{b} images/GPU x {world} GPU, {w}x{h} gray -> [B,3,{hp},{wp}] fp32, top-{k}, "
                                    f"border 15, nms 15 (BASELINE configs[3]/[4] shard)",
                        "global_batch": b * world, "parallelism": f"dp{world}", "precision": args.precision,
-                       "collective": "all_gather of [B,2K+1] int32 keypoint slabs" if world > 1 else "none"},
+                       "collective": collective_note},
             "roofline": head["roofline"],
             "forward_device_ms_per_step": head["forward_device_ms_per_step"],
             "nms_topk_device_ms_per_step": nms_ms,
             "forward_tflops": head["forward_tflops"],
+            "forward_hbm": head.get("forward_hbm"),
             "nms_topk_roofline": {"bound": "hbm", "achieved": nms_bytes / (nms_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                                   "unit": "GB/s", "frac": nms_bytes / (nms_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
             "kernels_ms_per_step": head["kernels_ms_per_step"],
             "other_precision": other,
+            "other_configs": other_cfgs,
         }
         if world == 1 and args.cpu_images > 0:
-            res["cpu_baseline"] = cpu_baseline(h, w, k, args.cpu_images, state, args.cpu_threads)
+            n = min(args.cpu_images, b)
+            res["cpu_baseline"], cpu_probs, cpu_dets = cpu_baseline(gray[:n], k, state, args.cpu_threads)
+            res["index_match"] = index_match(gpu_sample, cpu_probs, cpu_dets, h, w, k, top, left)
+            res["index_match"]["precision"] = args.precision
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
-    if dist is not None:
+            res["index_match"] = None
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+    if have_group:
         dist.barrier()
         dist.destroy_process_group()
 

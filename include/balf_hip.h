@@ -104,6 +104,15 @@ int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int 
                   int border, int nms_size, int K, int32_t *idx_dev, float *score_dev,
                   int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* The same selection with a caller-given threshold instead of the K-th largest score: `threshold != -1` of
+ * find_index_higher_scores (/root/reference/balf/utils/test_utils.py:74-95): the first K pixels in raster order
+ * with NMS score >= threshold (all of them if fewer reach it; count may be 0).  threshold must be > 0 and finite:
+ * with a threshold <= 0 every pixel qualifies and the answer is the first K raster indices -- no device work, the
+ * host mirror (balf_amd/utils/test_utils.py) returns those directly.  Same workspace as balf_nms_topk. */
+int balf_nms_threshold(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W,
+                       int border, int nms_size, float threshold, int K, int32_t *idx_dev, float *score_dev,
+                       int32_t *count_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* ---- greedy "SuperPoint" NMS of the demo path --------------------------------------
  * Replaces get_points_direct_from_score_map + nms_fast (+ soft_argmax_points), balf/utils/test_utils.py:97-215,
  * as called by demo/demo_match.py:45-57.  The score map of image b is prob[b, crop_y:+H, crop_x:+W] with a
@@ -200,6 +209,15 @@ int balf_repeatability(const double *src_dev, int ns, const double *dst_dev, int
                        double *errors_dev, int32_t *corr_s_dev, int32_t *corr_m_dev, void *workspace_dev,
                        size_t workspace_bytes, void *stream);
 int balf_apply_homography(const double *points_dev, int n, const double *h_dev, double *out_dev, void *stream);
+
+/* create_common_region_masks, balf/benchmark_test/geometry_tools.py:7-26 (callers: the HPatches evaluation, and the
+ * masks handed to compute_repeatability_with_maximum_filter, balf/utils/train_utils.py:170-196): the region of each
+ * image covered by the other under the homography h_dst_2_src (HOST pointer, 9 doubles row-major).  mask_src_dev
+ * [h_src, w_src] and mask_dst_dev [h_dst, w_dst] float64 in {0, 1}: cv2.warpPerspective of an all-ones image with a
+ * zeroed `border` frame (bilinear, zero outside, source coordinates rounded to 1/32 pixel), >= 0.75, frame zeroed
+ * again.  cv2 is absent from the build container: parity with it is unpinned. */
+int balf_common_region_masks(const double *h_dst_2_src_host, int h_src, int w_src, int h_dst, int w_dst, int border,
+                             double *mask_src_dev, double *mask_dst_dev, void *stream);
 
 /* ---- measurement aid (not part of the data path) ---------------------------------------------
  * Between balf_profile_begin() and balf_profile_end() every kernel launch of the library is bracketed

@@ -184,6 +184,12 @@ def select_topk(nms: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
     return idx.astype(np.int64), nms.ravel()[idx]
 
 
+def select_threshold(nms: np.ndarray, k: int, threshold: float) -> np.ndarray:
+    """``find_index_higher_scores(map, num_points=k, threshold=threshold)`` with ``threshold != -1``
+    (test_utils.py:91-95): flat indices, in raster order, of the first k pixels with value >= threshold."""
+    return np.flatnonzero(np.asarray(nms).ravel() >= threshold)[:k]
+
+
 def canonical_order(idx: np.ndarray, score: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """Score descending, flat index ascending among equal scores.  The reference's final
     ``argsort(-score)`` (train_utils.py:451) leaves the order of equal scores unspecified;
@@ -468,3 +474,46 @@ def compute_repeatability_with_maximum_filter(src_scores, dst_scores, homography
     r = compute_repeatability(pts[0], apply_homography_to_points(pts[1], homography))
     return ([r["rep_single_scale"]], [r["rep_multi_scale"]], [r["error_overlap_single_scale"]],
             [r["error_overlap_multi_scale"]], [r["possible_matches"]])
+
+
+# ----------------------------------------------------------------------------------------
+# common-region masks of the evaluation (geometry_tools.py:7-26)
+# ----------------------------------------------------------------------------------------
+def warp_perspective_linear(src: np.ndarray, m: np.ndarray, dsize) -> np.ndarray:
+    """cv2.warpPerspective(src, m, dsize) with its default flags (bilinear, BORDER_CONSTANT 0), restated from OpenCV's
+    algorithm for a float64 image: dst(x, y) = src(M^-1 (x, y, 1)); source coordinates rounded to 1/32 pixel
+    (INTER_TAB_SIZE 32, round half to even).  cv2 is not installed in the build container: this restatement is
+    PARITY UNPINNED against cv2 itself."""
+    w, h = int(dsize[0]), int(dsize[1])
+    mi = np.linalg.inv(np.asarray(m, dtype=np.float64))
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    wv = mi[2, 0] * xs + mi[2, 1] * ys + mi[2, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sc = np.where(wv != 0, 32.0 / wv, 0.0)
+    fx = np.clip((mi[0, 0] * xs + mi[0, 1] * ys + mi[0, 2]) * sc, -2147483648.0, 2147483647.0)
+    fy = np.clip((mi[1, 0] * xs + mi[1, 1] * ys + mi[1, 2]) * sc, -2147483648.0, 2147483647.0)
+    X, Y = np.rint(fx).astype(np.int64), np.rint(fy).astype(np.int64)
+    sx, sy = X >> 5, Y >> 5
+    ax, ay = (X & 31) / 32.0, (Y & 31) / 32.0
+    sh, sw = src.shape
+
+    def at(yy, xx):
+        ok = (yy >= 0) & (yy < sh) & (xx >= 0) & (xx < sw)
+        return np.where(ok, src[np.clip(yy, 0, sh - 1), np.clip(xx, 0, sw - 1)], 0.0)
+
+    return (at(sy, sx) * ((1 - ax) * (1 - ay)) + at(sy, sx + 1) * (ax * (1 - ay)) +
+            at(sy + 1, sx) * ((1 - ax) * ay) + at(sy + 1, sx + 1) * (ax * ay))
+
+
+def create_common_region_masks(h_dst_2_src, shape_src, shape_dst):
+    """geometry_tools.py:7-26 with ``warp_perspective_linear`` in the place of cv2.warpPerspective."""
+    h_dst_2_src = np.asarray(h_dst_2_src, dtype=np.float64)
+    inv_h = np.linalg.inv(h_dst_2_src)
+    inv_h = inv_h / inv_h[2, 2]
+    ones_dst = remove_borders(np.ones((shape_dst[0], shape_dst[1])), 15)
+    mask_src = warp_perspective_linear(ones_dst, h_dst_2_src, (shape_src[1], shape_src[0]))
+    mask_src = remove_borders(np.where(mask_src >= 0.75, 1.0, 0.0), 15)
+    ones_src = remove_borders(np.ones((shape_src[0], shape_src[1])), 15)
+    mask_dst = warp_perspective_linear(ones_src, inv_h, (shape_dst[1], shape_dst[0]))
+    mask_dst = remove_borders(np.where(mask_dst >= 0.75, 1.0, 0.0), 15)
+    return mask_src, mask_dst

@@ -132,6 +132,15 @@ def main():
         flat = (idxs[:, 0].astype(np.int64) * w + idxs[:, 1]).astype(np.int32)
         nk[name + ".idx"] = flat                       # raster order, as argwhere returns it
         nk[name + ".score"] = nms.ravel()[flat].astype(np.float32)
+        # the same selection with an explicit threshold (`threshold != -1`, test_utils.py:91-95): quantiles of the
+        # positive NMS values (fewer / more than k pixels reach them), a value nothing reaches, and <= 0 (every pixel)
+        pos = np.sort(nms.ravel()[nms.ravel() > 0])
+        thr = [float(pos[int(q * (pos.size - 1))]) for q in (0.1, 0.5, 0.9)] if pos.size else []
+        thr += [2.0, 0.0, -0.5]
+        nk[name + ".thr"] = np.asarray(thr, dtype=np.float64)
+        for j, t in enumerate(thr):
+            idt = RT.find_index_higher_scores(nms, num_points=spec["k"], threshold=t)
+            nk[f"{name}.thr{j}.idx"] = (idt[:, 0].astype(np.int64) * w + idt[:, 1]).astype(np.int32) if len(idt) else np.zeros(0, np.int32)
     np.savez_compressed(os.path.join(HERE, "nms_topk.npz"), **nk)
 
     # ---------------- greedy nms_fast path of the demo (no sub-pixel: torchgeometry is not installed) --------

@@ -2,7 +2,8 @@
 cfg1 32 x VGA top-1000, cfg2 64 x 720p top-2000 fp32, cfg3/cfg4 1080p shards (32 per GPU; 128 on one GPU, f16 path).
 Checked per configuration: (i) NMS/top-K of every image is bit-exact against the C oracle run on the very score
 map the GPU produced ("NMS indices bit-exact on identical input"), (ii) the batch is invisible (an image alone gives
-the same bits), (iii) every image yields its K keypoints, (iv) score map of one image against the CPU oracle."""
+the same bits), (iii) every image yields its K keypoints, (iv) the score map of one image against the CPU oracle at the configuration's
+full size (1088x1920 included) within 1e-4, (v) end-to-end top-K overlap with the oracle's own detections > 0.97."""
 import os
 import sys
 
@@ -70,9 +71,17 @@ def test_baseline_configuration(name, b, h, w, k, precision, oracle_images):
     with torch.inference_mode():
         i1, s1, c1, p1 = pipeline.detect_batch_u8(m, imgs[b - 1:b].contiguous(), 15, 15, k)
     assert torch.equal(p1[0], prob[b - 1]) and torch.equal(i1[0], idx[b - 1]) and torch.equal(s1[0], score[b - 1])
-    # (iv) score map of one image against the CPU oracle (fp32 torch ops), north_star tolerance 1e-4
-    if h <= 720:
-        g = imgs[1].cpu().numpy()
-        x = pipeline.pad_batch(synth.gray_to_rgb_norm(g)[None])
+    # (iv) score map of one image against the CPU oracle (fp32 torch ops) at the configuration's FULL size, north_star
+    #      tolerance 1e-4 (the oracle takes ~5 s per 1080p image on the box's host), and (v) the end-to-end keypoint
+    #      agreement: GPU score map -> GPU NMS/top-K against oracle score map -> C-oracle NMS/top-K (SURVEY 8d iii:
+    #      1e-5 of score-map noise moves ~0.6 % of the top-K set; the gate leaves room for that and no more)
+    g = imgs[1].cpu().numpy()
+    x = pipeline.pad_batch(synth.gray_to_rgb_norm(g)[None])
+    with torch.no_grad():
         ref = oracle.detector_forward(synth.synthetic_state_dict(cases.WEIGHT_SEED), x)["prob"][0].numpy()
-        assert np.abs(prob[1].cpu().numpy() - ref).max() < 1e-4
+    err = float(np.abs(prob[1].cpu().numpy() - ref).max())
+    ri, _, _ = c_oracle.nms_topk(np.ascontiguousarray(ref[top:top + h, left:left + w]), 15, 15, k)
+    overlap = len(set(ri.tolist()) & set(idx[1].cpu().numpy().tolist())) / float(k)
+    print(f"{name}: score map max-abs err vs oracle {err:.3e}, end-to-end top-{k} overlap {overlap:.4f}")
+    assert err < 1e-4, (name, err)
+    assert overlap > 0.97, (name, overlap)

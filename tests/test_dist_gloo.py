@@ -50,3 +50,29 @@ def test_allgather_is_identity_without_process_group():
     idx = torch.zeros((2, 5), dtype=torch.int32); sc = torch.zeros((2, 5)); cnt = torch.zeros(2, dtype=torch.int32)
     a, b, c = pipeline.allgather_keypoints(idx, sc, cnt)
     assert a is idx and b is sc and c is cnt
+
+
+def _single_worker(port, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        idx = torch.arange(10, dtype=torch.int32).view(2, 5); sc = torch.rand((2, 5)); cnt = torch.tensor([5, 3], dtype=torch.int32)
+        a, b, c = pipeline.allgather_keypoints(idx, sc, cnt)                 # single rank: shortcut
+        short = a is idx
+        a, b, c = pipeline.allgather_keypoints(idx, sc, cnt, force=True)     # forced: the collective runs
+        out_q.put(bool(short and a is not idx and torch.equal(a, idx) and torch.equal(b, sc) and torch.equal(c, cnt)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_single_rank_forced():
+    """world size 1 with ``force=True`` goes through pack -> all_gather_into_tensor -> unpack (the RCCL plumbing
+    test of the GPU box, tests/test_rccl_gpu.py, on gloo)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0

@@ -25,6 +25,7 @@ def model():
     from balf_amd.model import get_model
     m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
     m.load_state_dict(synth.synthetic_state_dict(cases.WEIGHT_SEED))
+    m.precision = "fp32"                # the exact-fp32 MFMA path (the module default is the split-f16 path)
     return m.eval().to("cuda:0")
 
 
@@ -231,3 +232,31 @@ def test_random_shapes_vs_oracle_and_uint8_identity(model, model16):
                 u = m.forward_u8(torch.from_numpy(img).to("cuda:0"), want_logits=False)["prob"]
             assert torch.equal(a, u), (case, h, w, rgb)
             assert np.abs(a.cpu().numpy() - ref).max() < tol, (case, h, w, rgb, m.precision)
+
+
+def _scaled_state(scale_stage_inputs: float):
+    """Synthetic weights with the un-normalised operands blown up: the RCAB output convolution of every stage (and with
+    it x2 = t*s + x1 + x0, the next stage's input and the head input) scaled by ``scale_stage_inputs``."""
+    sd = synth.synthetic_state_dict(cases.WEIGHT_SEED)
+    for s in range(1, 5):
+        for k in (f"down{s}.residual_channel_attention_block.conv2.weight", f"down{s}.residual_channel_attention_block.conv2.bias"):
+            sd[k] = sd[k] * scale_stage_inputs
+    return sd
+
+
+def test_f16_split_operand_range():
+    """split16.h: operands are carried as two f16 halves.  Activations far above the synthetic checkpoint's O(1) range
+    (stage inputs and head input scaled ~40x per stage) still agree with the exact-fp32 path; a checkpoint that leaves
+    the f16 range (+-6.5e4) is caught by validate_fp16 instead of returning garbage silently."""
+    from balf_amd._lib import BalfHipError
+    from balf_amd.model import get_model
+    x = cases.forward_input(2, 128, 192, 5).to("cuda:0")
+    m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m.load_state_dict(_scaled_state(40.0))
+    m = m.eval().to("cuda:0")
+    with torch.inference_mode():
+        err = m.validate_fp16(x, tol=PROB_TOL)
+    print("wide-range activations: f16-split vs fp32 score map", err)
+    m.load_state_dict(_scaled_state(3.0e4))
+    with torch.inference_mode(), pytest.raises(BalfHipError):
+        m.validate_fp16(x, tol=PROB_TOL)

@@ -151,6 +151,30 @@ def test_test_utils_mirror(dev):
     assert np.all(pts[:, 2] == 1.0)
 
 
+@pytest.mark.parametrize("name", list(cases.NMS_CASES))
+def test_explicit_threshold_golden(dev, name):
+    """`threshold != -1` of find_index_higher_scores / get_point_coordinates (test_utils.py:74-95) through the mirror
+    (balf_nms_threshold for positive thresholds) against the reference's own index lists, both coordinate orders."""
+    from balf_amd.utils import test_utils as T
+    f = np.load(os.path.join(G, "nms_topk.npz"))
+    spec = cases.NMS_CASES[name]
+    score = cases.nms_input(spec)
+    w = score.shape[1]
+    nms = O.apply_nms(O.remove_borders(score, spec["border"]), spec["nms"])
+    for j, t in enumerate(f[name + ".thr"]):
+        ref = f[f"{name}.thr{j}.idx"]
+        ind = T.find_index_higher_scores(nms, num_points=spec["k"], threshold=float(t))
+        assert ind.shape == (ref.size, 2), (name, t, ind.shape, ref.size)
+        assert np.array_equal((ind[:, 0] * w + ind[:, 1]).astype(np.int32), ref), (name, t)
+        for order in ("xysr", "yxsr"):
+            pts = T.get_point_coordinates(nms, num_points=spec["k"], threshold=float(t), order_coord=order)
+            assert pts.shape == (ref.size, 4)
+            if ref.size:
+                c, r = (0, 1) if order == "xysr" else (1, 0)
+                assert np.array_equal((pts[:, r] * w + pts[:, c]).astype(np.int32), ref)
+                assert np.array_equal(pts[:, 3].astype(np.float32), nms.ravel()[ref])
+
+
 def test_random_sweep_vs_c_oracle(dev):
     """120 seeded random configurations -- odd sizes down to 1 x 1, every window size, borders that swallow the whole
     map, K from 1 to H*W, tie-heavy / sparse / zero maps, batches with crops -- bit-exact against the C oracle."""

@@ -89,6 +89,16 @@ def test_nms_topk_cases(name):
     assert np.array_equal(np.sort(ci), idx) and np.all(np.diff(cs.astype(np.float64)) <= 0)
 
 
+@pytest.mark.parametrize("name", list(cases.NMS_CASES))
+def test_explicit_threshold_cases(name):
+    """`threshold != -1` of find_index_higher_scores (test_utils.py:91-95) against the reference's own outputs."""
+    f = np.load(os.path.join(G, "nms_topk.npz"))
+    spec = cases.NMS_CASES[name]
+    nms = O.apply_nms(O.remove_borders(cases.nms_input(spec), spec["border"]), spec["nms"])
+    for j, t in enumerate(f[name + ".thr"]):
+        assert np.array_equal(O.select_threshold(nms, spec["k"], float(t)).astype(np.int32), f[f"{name}.thr{j}.idx"]), (name, t)
+
+
 def test_topk_more_points_than_pixels_is_index_error():
     with pytest.raises(IndexError):
         O.select_topk(np.ones((4, 4), np.float32), 17)

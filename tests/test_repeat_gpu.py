@@ -75,3 +75,29 @@ def test_evaluation_glue_matches_reference_golden():
                                                                 cases.EVAL_CASE["num_points"])
     assert len(res) == 5 and all(isinstance(v, list) and len(v) == 1 for v in res)
     assert np.allclose([float(np.asarray(v[0])) for v in res], g["eval.result"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("shape_src,shape_dst,hm", [
+    ((240, 320), (240, 320), cases.HOMOGRAPHY),
+    ((480, 640), (400, 600), [[0.93, -0.11, 31.0], [0.08, 1.04, -12.5], [1.2e-4, -6.0e-5, 1.0]]),
+    ((200, 260), (300, 280), [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]),
+    ((120, 160), (120, 160), [[0.5, 0.0, 200.0], [0.0, 0.5, 200.0], [0.0, 0.0, 1.0]]),       # no overlap at all
+])
+def test_common_region_masks_vs_oracle(shape_src, shape_dst, hm):
+    """create_common_region_masks (geometry_tools.py:7-26).  The reference computes the masks with cv2.warpPerspective,
+    which is not installed here: the HIP kernel and the oracle both restate OpenCV's algorithm (parity with cv2 itself
+    UNPINNED); they must agree everywhere except where a source coordinate falls within rounding of a 1/32-pixel tie."""
+    hm = np.asarray(hm, dtype=np.float64)
+    ms, md = geometry_tools.create_common_region_masks(hm, shape_src, shape_dst)
+    rs, rd = oracle.create_common_region_masks(hm, shape_src, shape_dst)
+    assert ms.shape == tuple(shape_src) and md.shape == tuple(shape_dst) and ms.dtype == np.float64
+    assert set(np.unique(ms)) <= {0.0, 1.0} and set(np.unique(md)) <= {0.0, 1.0}
+    assert ms[:15].sum() == 0 and ms[:, :15].sum() == 0 and md[-15:].sum() == 0 and md[:, -15:].sum() == 0
+    for a, b in ((ms, rs), (md, rd)):
+        assert (a != b).sum() <= 4, int((a != b).sum())              # differently rounded matrix inverses at a tie
+
+
+def test_common_region_masks_identity_is_the_inner_frame():
+    ms, md = geometry_tools.create_common_region_masks(np.eye(3), (100, 140), (100, 140))
+    ref = np.zeros((100, 140)); ref[15:85, 15:125] = 1.0
+    assert np.array_equal(ms, ref) and np.array_equal(md, ref)

@@ -1,6 +1,5 @@
-mkdir -p gpurun_out/r2e
-python tools/check_f16.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r2e/check.txt
-grep -q "equal: False" gpurun_out/r2e/check.txt && { echo "NONDETERMINISTIC - stop"; exit 1; }
-python tools/bench_kernels.py fp16 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r2e/bk.txt
-timeout 900 python -m pytest tests/test_forward_gpu.py -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/r2e/pytest_fwd.txt
-python tools/bench_kernels.py fp16 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r2e/bk.txt
+set -x
+mkdir -p gpurun_out/r2f
+timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 | tee gpurun_out/r2f/pytest_gpu.txt
+python bench.py > gpurun_out/r2f/bench.json 2> gpurun_out/r2f/bench.err; tail -3 gpurun_out/r2f/bench.err; python -c "
+import json;d=json.load(open('gpurun_out/r2f/bench.json'));print({k:d[k] for k in ('value','ms_per_step','index_match','other_configs','config')});print(d['roofline']);print(d.get('forward_hbm'))"

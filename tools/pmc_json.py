@@ -1,0 +1,82 @@
+"""profiles/rN_pmc.json from the rocprofv3 --pmc passes of tools/pmc_profile.sh: per bench profile slot (the names
+bench.py's hipEvent timing uses) the measured HBM bytes per launch and the issue-slot accounting of the kernel.
+
+  hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   FETCH_SIZE counts 64 B per 128-B request for wide streaming
+                                                                reads on gfx950 (MI355X_MICROARCH.md, HBM section); KiB units
+  issue_share          = (VALU instructions * 3.2 + MFMA instructions * C) / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
+                         3.2 cycles per wave64 VALU instruction with >= 2 waves on a SIMD (tools/ubench/valu_issue.hip),
+                         C = 16 (v_mfma_f32_16x16x32_f16) or 32 (v_mfma_f32_16x16x4_f32); GRBM_GUI_ACTIVE sums the 8 XCDs
+  wave_wait_share      = SQ_WAIT_ANY / SQ_WAVE_CYCLES       (parked at s_waitcnt / s_barrier)
+  wave_issue_stall_share = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (an instruction ready, the pipe not)
+
+usage: python tools/pmc_json.py <dir with fp16/ and fp32/ pass directories> <out.json>"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+root, out = sys.argv[1], sys.argv[2]
+
+
+def slot_of(kernel: str):
+    k = kernel.replace("(anonymous namespace)::", "").replace("void ", "").replace("balf::", "").split("(")[0]
+    m = re.match(r"stage1_kernel16<(\d)", k)
+    if m:
+        return "stage1_%s_branch" % ("grid" if m.group(1) == "0" else "block")
+    m = re.match(r"stage_branch_kernel(?:16)?(?:_ns)?<(\d+), \d+, (\d)>", k)
+    if m:
+        return "stage%d_%s_branch" % ([32, 64, 128, 256].index(int(m.group(1))) + 1, "grid" if m.group(2) == "0" else "block")
+    m = re.match(r"pool_kernel(?:16)?<(\d+)>", k)
+    if m:
+        return "stage%d_pool" % ([32, 64, 128].index(int(m.group(1))) + 1)
+    m = re.match(r"se_(?:reduce_)?kernel<(\d+)>", k)
+    if m:
+        return "stage%d_se" % ([32, 64, 128, 256].index(int(m.group(1))) + 1)
+    if k.startswith("head_kernel"):
+        return "stage4_head"
+    if "nms_tile_kernel" in k:
+        return "nms_tile"
+    if "topk_select_kernel" in k:
+        return "topk_select"
+    return None
+
+
+res = {}
+for prec in ("fp16", "fp32"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))       # slot -> counter -> sum over kernels of avg per dispatch
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(f"{root}/{prec}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            v = per_kernel[r["Kernel_Name"]][r["Counter_Name"]]
+            v[0] += float(r["Counter_Value"]); v[1] += 1
+    kernels = collections.defaultdict(list)
+    for kname, ctrs in per_kernel.items():
+        s = slot_of(kname)
+        if s is None:
+            continue
+        kernels[s].append(kname.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0])
+        for c, (tot, n) in ctrs.items():
+            acc[s][c] += tot / n
+    mfma_cycles = 16.0 if prec == "fp16" else 32.0
+    slots = {}
+    for s, c in sorted(acc.items()):
+        d = {"kernels": sorted(set(kernels[s])),
+             "hbm_bytes_per_launch": (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0,
+             "fetch_kib_raw": c.get("FETCH_SIZE", 0.0), "write_kib": c.get("WRITE_SIZE", 0.0)}
+        if c.get("SQ_WAVE_CYCLES"):
+            simd_cycles = 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
+            d.update({"waves": c["SQ_WAVES"], "valu_insts": c["SQ_INSTS_VALU"], "mfma_insts": c.get("SQ_INSTS_MFMA", 0.0),
+                      "issue_share": (c["SQ_INSTS_VALU"] * 3.2 + c.get("SQ_INSTS_MFMA", 0.0) * mfma_cycles) / simd_cycles,
+                      "wave_wait_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                      "wave_issue_stall_share": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                      "valu_active_share": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                      "gpu_cycles": c["GRBM_GUI_ACTIVE"] / 8.0})
+        slots[s] = d
+    res[prec] = slots
+json.dump({"command": "tools/pmc_profile.sh: per precision three rocprofv3 --kernel-trace --pmc passes of "
+                      "`python3 bench.py --steps 1 --warmup 1 --batch-per-gpu 8 --cpu-images 0 --other-steps 0 --other-configs 0` "
+                      "(1088x1920, 8 images per launch): SQ counters + GRBM_GUI_ACTIVE, FETCH_SIZE, WRITE_SIZE",
+           "definitions": __doc__, "slots": res}, open(out, "w"), indent=1)
+print(out)
