@@ -299,9 +299,9 @@ def main():
                 "hbm": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h,
                         "algorithmic_bytes_per_launch": nbytes}}
         if slot:
-            # vector + matrix instructions of one launch priced at what a SIMD sustains (3.2 cycles per VALU instruction
-            # with >= 2 waves, 16 per 16x16x32 f16 MFMA / 32 per 16x16x4 f32 MFMA; tools/ubench/valu_issue.hip) over the
-            # SIMD cycles of the launch in the same profiled run
+            # vector + matrix instructions of one launch priced at what a SIMD charges with >= 2 waves resident (2.6 cycles
+            # per VALU instruction, 12.5 per 16x16x32 f16 MFMA beside vector work / 32 per 16x16x4 f32 MFMA;
+            # tools/ubench/mfma_valu_mix.hip) over the SIMD cycles of the launch in the same profiled run
             roof["issue"] = {k_: slot[k_] for k_ in ("valu_insts", "mfma_insts", "issue_share", "wave_wait_share",
                                                      "wave_issue_stall_share", "waves") if k_ in slot}
         share = (slot or {}).get("issue_share", 0.0)

@@ -17,7 +17,9 @@
  * Conventions: plain pointers and sizes only.  Every device buffer (inputs, outputs, workspace)
  * is owned by the caller; the library never allocates or frees device memory, never calls
  * hipDeviceSynchronize, and enqueues all work on the hipStream_t passed as `stream`
- * (as void*; NULL = the null stream).  Every function returns BALF_OK (0) or a negative
+ * (as void*; NULL = the null stream).  It does not synchronise the stream either, with two exceptions whose
+ * work is data dependent and that say so where they are declared: balf_greedy_nms (hipStreamSynchronize once per
+ * group of 4 suppression rounds) and balf_repeatability (once, for the candidate count).  Every function returns BALF_OK (0) or a negative
  * BALF_ERR_* code and never throws.  Shapes are validated on the host before any launch.
  */
 #ifndef BALF_HIP_H
