@@ -390,6 +390,13 @@ __device__ unsigned long long g_stamp_cnt[16];
 #define STAMP_DECL
 #define STAMP(i)
 #endif
+// add the value of lane (l + n) mod 16 of the same 16-lane row (DPP row_ror): 4 steps = sum over the row in every lane
+template <int N>
+__device__ __forceinline__ float row_ror_add(float v) {
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, r);
+}
+
 constexpr int kBtPitch16 = kTokens + 8;        // halves per channel row of the transposed token tile
 
 #ifndef BALF_COOP_MIN_C
@@ -780,21 +787,14 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
                 if (!BALF_ABLATE_STORE || t[nt][p][0] == 1.2345e-33f) *reinterpret_cast<f4 *>(A.T + pix[p] * C + 16 * nt + 4 * q) = t[nt][p];
                 s += t[nt][p];
             }
+            // channel sums of this wave's 16 * P pixels (fixed order): one partial row per WAVE, straight to HBM -- the
+            // cross-wave sum used to cost a workgroup barrier at the very end of the kernel (6 % of the C = 64 kernel);
+            // se_reduce_kernel adds the four rows with the rest
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[r];
-                v += __shfl_xor(v, 1, 64);
-                v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64);
-                v += __shfl_xor(v, 8, 64);
-                if (li == 0) red[wave * C + 16 * nt + 4 * q + r] = v;
-            }
+            for (int r = 0; r < 4; ++r) s[r] = row_ror_add<1>(row_ror_add<2>(row_ror_add<4>(row_ror_add<8>(s[r]))));
+            if (li == 0) *reinterpret_cast<f4 *>(A.partial + ((long)item * 4 + wave) * C + 16 * nt + 4 * q) = s;
         }
         STAMP(13);  // conv2, T store, channel sums
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256)
-            A.partial[(long)item * C + c] = (red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c]);
-        STAMP(14);  // partial sums out
     }
 }
 
@@ -1446,6 +1446,7 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
         BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(n0, dim3(nwg), dim3(512), nlds, st, a));
         BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(n1, dim3(nwg), dim3(512), nlds, st, a));
     } else {
+        per_img *= 4;                                      // generic kernels: one partial-sum row per wave
         BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(k0, dim3(nwg), dim3(256), lds, st, a));
         BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(k1, dim3(nwg), dim3(256), lds, st, a));
     }

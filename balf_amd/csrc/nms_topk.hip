@@ -270,16 +270,37 @@ __device__ unsigned radix_select(int n, int rank, bool cached, const int2 (&ent)
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int cum = 0, chosen = 0, r = rank;
-            for (int t = 0; t < 256; ++t) {
-                const int bin = FROM_TOP ? 255 - t : t;
-                const int h = (int)s_hist[bin];
-                if (cum + h >= r) { chosen = bin; r -= cum; s_tmp[2] = h; break; }
-                cum += h;
+        if (threadIdx.x < 64) {
+            // first bin (in scan order) at which the running count reaches `rank`: wave 0, four bins per lane, a
+            // shuffle prefix over the lanes (the scan used to be 256 serial LDS reads on thread 0, four times per select)
+            const int l = threadIdx.x;
+            int h[4], sum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 4 * l + i;
+                h[i] = (int)s_hist[FROM_TOP ? 255 - t : t];
+                sum += h[i];
             }
-            s_tmp[0] = chosen;
-            s_tmp[1] = r;
+            int inc = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(inc, d, 64);
+                if (l >= d) inc += v;
+            }
+            int cum = inc - sum;
+            if (cum < rank && rank <= inc) {                 // exactly one lane
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (cum + h[i] >= rank) {
+                        const int t = 4 * l + i;
+                        s_tmp[0] = FROM_TOP ? 255 - t : t;
+                        s_tmp[1] = rank - cum;
+                        s_tmp[2] = h[i];
+                        break;
+                    }
+                    cum += h[i];
+                }
+            }
         }
         __syncthreads();
         prefix |= (unsigned)s_tmp[0] << shift;

@@ -147,13 +147,6 @@ __device__ __forceinline__ void s1_bias(f4 (&t)[NT][P], const float *par, int q)
     }
 }
 
-// add the value of lane (l + n) mod 16 of the same 16-lane row (DPP row_ror): 4 steps = sum over the row in every lane
-template <int N>
-__device__ __forceinline__ float row_ror_add(float v) {
-    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true);
-    return v + __builtin_bit_cast(float, r);
-}
-
 // Vector-memory discipline of the float-input kernels (U8 = false).  vmcnt counts loads and stores together, in issue
 // order, and the compiler drains it to zero at the loop's back edge as soon as it has a load of its own pending -- which
 // makes every group wait for the previous group's 8-16 KiB of stores (measured: 40 % of the grid kernel's time).  So every
