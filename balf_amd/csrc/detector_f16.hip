@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     constexpr int main_bytes =
         stage_lds_bytes16<C, P>() - 4 * C * 4 - (use_ring<C>() ? kRingBytes : 0) - par_floats<C>() * 4;
     _Float16 *bT = reinterpret_cast<_Float16 *>(smem_raw);                 // [hi|lo][p][c][pitch]
-    float *red = reinterpret_cast<float *>(smem_raw + main_bytes);         // [4][C]
+    // (smem_raw + main_bytes: 4 * C floats, formerly the cross-wave channel-sum scratch; kept so the LDS image is unchanged)
     unsigned char *ring = smem_raw + main_bytes + 4 * C * 4;               // weight ring (C >= 64)
     float *par = reinterpret_cast<float *>(smem_raw + main_bytes + 4 * C * 4 + (use_ring<C>() ? kRingBytes : 0));
 
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     constexpr int slots_b = 4 * KS * P * 2048, bt_b = 2 * P * C * kBtPitch16 * 2;
     constexpr int main_bytes = slots_b > bt_b ? slots_b : bt_b;
     _Float16 *bT = reinterpret_cast<_Float16 *>(smem_raw);                 // [hi|lo][p][c][pitch]
-    float *red = reinterpret_cast<float *>(smem_raw + main_bytes);         // [4][C]
+    // (smem_raw + main_bytes: 4 * C floats, formerly the cross-wave channel-sum scratch; kept so the LDS image is unchanged)
     unsigned char *ring = smem_raw + main_bytes + 4 * C * 4;
     float *par = reinterpret_cast<float *>(smem_raw + main_bytes + 4 * C * 4 + kNsRingBytes);
     float *lnx = par + par_floats<C>();
@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     f4 z[NTL][P];
     init_bias(z, par + kParQ1B * C + 16 * nt0, q);
     G(I1{}, z, from_slot);
-    gelu<false, (C == 128)>(z);
+    gelu<false, (C == 128 && MODE == 1)>(z);
     {
         f4 h[NTL][P];
         ln_plain(z, h);
@@ -1145,12 +1145,12 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     f4 ga[NTL][P];
     init_bias(ga, par + kParD1B * C + 16 * nt0, q);
     G(I2{}, ga, from_slot);
-    gelu<false, (C == 128)>(ga);
+    gelu<false, (C == 128 && MODE == 1)>(ga);
     {
         f4 gb[NTL][P];
         init_bias(gb, par + kParD1B * C + C + 16 * nt0, q);
         G(I3{}, gb, from_slot);
-        gelu<false, (C == 128)>(gb);
+        gelu<false, (C == 128 && MODE == 1)>(gb);
         {
             float mean[P], rstd[P];
             ln_stats_ns<NTL, P>(gb, lnx, pg, hh, q, li, mean, rstd);
@@ -1272,19 +1272,11 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
                 *reinterpret_cast<f4 *>(A.T + pix[p] * C + 16 * (nt0 + nt) + 4 * q) = t[nt][p];
                 ssum += t[nt][p];
             }
+            // one partial row per wave PAIR (each wave its half of the channels), straight to HBM: no final barrier
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = ssum[r];
-                v += __shfl_xor(v, 1, 64);
-                v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64);
-                v += __shfl_xor(v, 8, 64);
-                if (li == 0) red[pg * C + 16 * (nt0 + nt) + 4 * q + r] = v;
-            }
+            for (int r = 0; r < 4; ++r) ssum[r] = row_ror_add<1>(row_ror_add<2>(row_ror_add<4>(row_ror_add<8>(ssum[r]))));
+            if (li == 0) *reinterpret_cast<f4 *>(A.partial + ((long)item * 4 + pg) * C + 16 * (nt0 + nt) + 4 * q) = ssum;
         }
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 512)
-            A.partial[(long)item * C + c] = (red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c]);
     }
 }
 
@@ -1443,6 +1435,7 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
             hipFuncSetAttribute(reinterpret_cast<const void *>(n1), hipFuncAttributeMaxDynamicSharedMemorySize, nlds) !=
                 hipSuccess)
             return BALF_ERR_LAUNCH;
+        per_img *= 4;                                      // one partial-sum row per wave pair
         BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(n0, dim3(nwg), dim3(512), nlds, st, a));
         BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(n1, dim3(nwg), dim3(512), nlds, st, a));
     } else {
