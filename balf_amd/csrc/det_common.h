@@ -308,29 +308,29 @@ constexpr int stage_lds_bytes() {
 // ------------------------------------------------------------------------------------------------
 // squeeze-excite: s[n, :] = sigmoid(W2 relu(W0 mean_hw(t) + b0) + b2)   (mlp_ma_decoder.py:166-171)
 // ------------------------------------------------------------------------------------------------
-// Level 1: [B, per_img, C] workgroup sums -> [B, kSeChunks, C] chunk sums (fixed order: deterministic).
-constexpr int kSeChunks = 64;
+// Level 1: [B, per_img, C] partial sums -> [B, kSeChunks, C] chunk sums (fixed order: deterministic).  A thread owns four
+// adjacent channels (16-byte loads); the 256 / (C/4) row groups of a block stride over the chunk's rows.
+constexpr int kSeChunks = 128;
 
 template <int C>
 __global__ __launch_bounds__(256) void se_reduce_kernel(const float *__restrict__ partial, int per_img,
                                                         float *__restrict__ chunk) {
-    constexpr int PARTS = 256 / C > 0 ? 256 / C : 1;
-    __shared__ float s_part[PARTS][C];
+    constexpr int LANES = C / 4;                       // threads per row
+    constexpr int PARTS = 256 / LANES;                 // rows in flight per block (>= 4 for C <= 256)
+    __shared__ f4 s_part[PARTS][LANES];
     const int n = blockIdx.x / kSeChunks, ch = blockIdx.x % kSeChunks;
     const int per_chunk = (per_img + kSeChunks - 1) / kSeChunks;
     const int i0 = ch * per_chunk, i1 = (i0 + per_chunk < per_img) ? i0 + per_chunk : per_img;
     const float *pp = partial + (long)n * per_img * C;
-    {
-        const int c = threadIdx.x % C, part = threadIdx.x / C;       // 256 threads = PARTS x C exactly
-        float acc = 0.0f;
-        for (int i = i0 + part; i < i1; i += PARTS) acc += pp[(long)i * C + c];
-        s_part[part][c] = acc;
-    }
+    const int c4 = threadIdx.x % LANES, part = threadIdx.x / LANES;
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = i0 + part; i < i1; i += PARTS) acc += *reinterpret_cast<const f4 *>(pp + (long)i * C + 4 * c4);
+    s_part[part][c4] = acc;
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc = 0.0f;
-        for (int k = 0; k < PARTS; ++k) acc += s_part[k][c];
-        chunk[((long)n * kSeChunks + ch) * C + c] = acc;
+    if (threadIdx.x < LANES) {
+        f4 t = s_part[0][threadIdx.x];
+        for (int k = 1; k < PARTS; ++k) t += s_part[k][threadIdx.x];
+        *reinterpret_cast<f4 *>(chunk + ((long)n * kSeChunks + ch) * C + 4 * threadIdx.x) = t;
     }
 }
 
