@@ -54,7 +54,11 @@ __device__ __forceinline__ void store_slot16(h8 *slot, const f4 (&t)[NT][P], int
 }
 
 // pre-split activation row in HBM ("fragment format"): pixel base + ks*128 + {0: hi, 64: lo} + q*16 bytes
+#ifndef BALF_ABLATE_LOADLAT
+#define BALF_ABLATE_LOADLAT 0     // timing experiment: activation rows come from a small L2-resident window (wrong results)
+#endif
 __device__ __forceinline__ HL load_frag_px(const float *base, long pix, int C, int ks, int q) {
+    if (BALF_ABLATE_LOADLAT) pix &= 4095;
     const char *p = reinterpret_cast<const char *>(base) + pix * (long)C * 4 + ks * 128 + q * 16;
     HL o;
     o.hi = *reinterpret_cast<const h8 *>(p);

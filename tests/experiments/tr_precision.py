@@ -1,4 +1,4 @@
-"""CPU experiment (development aid; imports the oracle, so it is a tool, not product code): score-map error when the
+"""CPU experiment (test infrastructure: it drives the oracle, so it lives under tests/): score-map error when the
 inter-kernel activations T (RCAB body) and R (= x1 + x0) are stored in fewer bytes.  Monkey-patches the oracle's stage
 to round t and r before x2 = t*s + r.  Formats: f16 (2 B), bf16 (2 B), f16 hi + f16 lo (4 B, what fp32 storage gives),
 'f16s': f16 with a per-channel power-of-two scale (no gain expected), 'e5m10+8' = f16 hi + 8-bit residual (3 B)."""
