@@ -239,13 +239,42 @@ __device__ __forceinline__ void chain_issue(const RingChain &c, unsigned char *r
 //   s_barrier        -> every wave's part of unit G is visible, nobody reads slot (G-1) & 3 any more;
 //   issue DMA of unit G+3 into slot (G-1) & 3;  ds_read unit G;  MFMAs.
 // (A variant that read unit G+1's fragments during unit G's MFMAs measured no faster and costs 32 VGPRs.)
-__device__ __forceinline__ void ring_wait_barrier(int after /* units issued after the awaited one */) {
-    // wait + barrier are ONE asm statement with a memory clobber: the raw s_barrier builtin is IntrNoMem, so
-    // the compiler could otherwise move LDS accesses across it
-    if (BALF_RING_STRICT || after <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (after == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+// Other vector-memory operations in the queue.  vmcnt counts loads, stores and LDS-DMA together, in issue order, so a
+// batch of E ordinary loads / stores issued between ring iterations a and a+1 sits BEHIND the DMAs of units <= a+3
+// (issued three iterations ahead) and in front of all later ones: the waits for units a+1 .. a+3 may leave E more
+// operations outstanding -- without that allowance they drain the batch (the u' rows requested just before RSHMAG.dense2,
+// the R stores before the RCAB: an ablation build priced them at 5-7 % of the block kernels).  A GEMM is told E and how
+// many of the three waits were already USED by the GEMMs since the batch (compile-time tags: VmTag<E, USED>).
+#ifndef BALF_RING_VMEXTRA
+#define BALF_RING_VMEXTRA 1
+#endif
+template <int E, int USED> struct VmTag { static constexpr int e = E, used = USED; };
+using VmNone = VmTag<0, 3>;
+
+// s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier -- ONE asm statement with a memory clobber: the raw s_barrier builtin is
+// IntrNoMem, so the compiler could otherwise move LDS accesses across it
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory");
 }
+
+// PER = DMA instructions per ring unit and wave; `after` = units issued after the awaited one (two at most are in flight)
+template <int PER, int E>
+__device__ __forceinline__ void ring_wait(int after, bool extra) {
+    if (BALF_RING_STRICT) { wait_vm_barrier<0>(); return; }
+    if (E > 0 && BALF_RING_VMEXTRA && extra) {
+        if (after <= 0) wait_vm_barrier<E>();
+        else if (after == 1) wait_vm_barrier<PER + E>();
+        else wait_vm_barrier<2 * PER + E>();
+    } else {
+        if (after <= 0) wait_vm_barrier<0>();
+        else if (after == 1) wait_vm_barrier<PER>();
+        else wait_vm_barrier<2 * PER>();
+    }
+}
+
+__device__ __forceinline__ void ring_wait_barrier(int after) { ring_wait<2, 0>(after, false); }
 
 template <int NTC>
 __device__ __forceinline__ void ring_read(HL (&a)[NTC], const unsigned char *ring, int g, int lane) {
@@ -283,7 +312,7 @@ __device__ __forceinline__ void ring_mfma(f4 (&acc)[NTT][P], const HL (&a)[kRing
         for (int p = 0; p < P; ++p) acc[CI * kRingNTC + nt][p] = mfma16(a[nt].hi, b[p].hi, acc[CI * kRingNTC + nt][p]);
 }
 
-template <int NTT, int CI, int P, typename BL>
+template <int NTT, int CI, int P, typename VM, typename BL>
 __device__ __forceinline__ void chain_chunk(f4 (&acc)[NTT][P], const RingChain &c, unsigned char *ring, int gu,
                                             int lane, int wave, BL bload) {
     if constexpr (CI * kRingNTC < NTT) {
@@ -291,7 +320,7 @@ __device__ __forceinline__ void chain_chunk(f4 (&acc)[NTT][P], const RingChain &
         const int later = c.tot[1] + c.tot[2] + c.tot[3];
         for (int k = 0; k < ksn; ++k) {
             const int u = CI * ksn + k;
-            ring_wait_barrier(c.tot[0] - 1 - u + later);
+            ring_wait<2, VM::e>(c.tot[0] - 1 - u + later, u + VM::used < 3);
             chain_issue(c, ring, u + kRingSlots - 1, (gu + u + kRingSlots - 1) & (kRingSlots - 1), wave, lane);
             HL a[kRingNTC], b[P];
             ring_read<kRingNTC>(a, ring, gu + u, lane);
@@ -299,17 +328,17 @@ __device__ __forceinline__ void chain_chunk(f4 (&acc)[NTT][P], const RingChain &
             for (int p = 0; p < P; ++p) b[p] = bload(k, p);
             ring_mfma<NTT, CI, P>(acc, a, b);
         }
-        chain_chunk<NTT, CI + 1, P>(acc, c, ring, gu, lane, wave, bload);
+        chain_chunk<NTT, CI + 1, P, VM>(acc, c, ring, gu, lane, wave, bload);
     }
 }
 
 // Run chain.g[0].  `gu` = global index of its unit 0 (advanced here).  All four waves call this together;
 // the first three units of the kernel's sequence were issued in the prologue.
-template <int NTT, int P, typename BL>
+template <int NTT, int P, typename VM = VmNone, typename BL>
 __device__ __forceinline__ void gemm16_chain(f4 (&acc)[NTT][P], const RingChain &c, int &gu, int lane, int wave,
                                              unsigned char *ring, BL bload) {
     static_assert(NTT % kRingNTC == 0, "row tiles must come in groups of 4");
-    chain_chunk<NTT, 0, P>(acc, c, ring, gu, lane, wave, bload);
+    chain_chunk<NTT, 0, P, VM>(acc, c, ring, gu, lane, wave, bload);
     gu += c.tot[0];
 }
 
@@ -470,6 +499,8 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
 
     // the Linears of this kernel in execution order (the weight ring prefetches across them)
     constexpr int NG = (MODE == 0) ? 6 : 10;
+    // ring-wait allowances (VmTag): u' loads per wave, R stores per wave, ring units of one C -> C Linear
+    constexpr int EU = KS * P * 2, ER = NT * P, UG = (NT / kRingNTC > 0 ? NT / kRingNTC : 1) * KS;
     const char *bb = reinterpret_cast<const char *>(blob);
     RingGemm seq[NG + 3];
     {
@@ -560,12 +591,12 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     if constexpr (!use_ring<C>() && NT == 2) wpre = wpre_load(seq[1], lane);
     // every Linear goes through G: chained LDS-ring version for C >= 64, per-wave streaming otherwise.
     // The Linears of this kernel in execution order (the ring prefetches across them):
-    auto G = [&](auto idx, auto &acc, auto bload) {
+    auto G = [&](auto idx, auto &acc, auto bload, auto vm) {
         constexpr int I = decltype(idx)::value;
         const RingGemm &d = seq[I];
         if constexpr (use_ring<C>()) {
             const RingChain c = make_chain<NT>(seq[I], seq[I + 1], seq[I + 2], seq[I + 3], NG - I);
-            gemm16_chain<NT, P>(acc, c, gu, lane, wave, ring, bload);            // ring primed in the prologue
+            gemm16_chain<NT, P, decltype(vm)>(acc, c, gu, lane, wave, ring, bload);   // ring primed in the prologue
         } else if constexpr (NT == 2) {
             gemm16_single<P>(acc, wpre, bload);
             constexpr int NX = (I + 1 == 4) ? I + 2 : I + 1;          // entry 4 is the token-mix matrix
@@ -610,9 +641,9 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
                 o.hi = slot[((kk * P + p) * 2 + 0) * 64 + lane];
                 o.lo = slot[((kk * P + p) * 2 + 1) * 64 + lane];
                 return o;
-            });
+            }, VmNone{});
         } else {
-            G(I0{}, x0, [&](int kk, int p) { return load_frag_px(A.X, pix[p], CIN, kk, q); });
+            G(I0{}, x0, [&](int kk, int p) { return load_frag_px(A.X, pix[p], CIN, kk, q); }, VmNone{});
         }
         relu(x0);
     }
@@ -631,7 +662,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     };
     f4 z[NT][P];
     init_bias(z, par + kParQ1B * C, q);
-    G(I1{}, z, from_slot);
+    G(I1{}, z, from_slot, VmNone{});
     gelu<PK>(z);
     STAMP(3);   // dense1 half + GELU
 
@@ -643,13 +674,13 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     STAMP(4);   // LN + slot
     f4 ga[NT][P];
     init_bias(ga, par + kParD1B * C, q);
-    G(I2{}, ga, from_slot);
+    G(I2{}, ga, from_slot, VmNone{});
     gelu<PK>(ga);
     STAMP(5);   // branch dense1 (a half) + GELU
     {
         f4 gb[NT][P];
         init_bias(gb, par + kParD1B * C + C, q);
-        G(I3{}, gb, from_slot);
+        G(I3{}, gb, from_slot, VmNone{});
         gelu<PK>(gb);
         layernorm<PK>(gb, gb, par + kParGlnG * C, par + kParGlnB * C, q);
         STAMP(6);   // branch dense1 (b half) + GELU + LN
@@ -723,7 +754,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
     store_slot16(slot, ga, lane);
     f4 o[NT][P];
     init_bias(o, par + kParD2B * C, q);
-    G(I5{}, o, from_slot);
+    G(I5{}, o, from_slot, VmNone{});
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -748,7 +779,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
             for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
                 for (int p = 0; p < P; ++p) ub[kk][p] = load_frag_px(A.U, pix[p], C, kk, q);
-            G(I6{}, x1, from_slot);
+            G(I6{}, x1, from_slot, VmTag<EU, 0>{});            // the u' loads may stay in flight
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
@@ -756,10 +787,10 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
                     slot[((kk * P + p) * 2 + 0) * 64 + lane] = ub[kk][p].hi;
                     slot[((kk * P + p) * 2 + 1) * 64 + lane] = ub[kk][p].lo;
                 }
-            G(I7{}, x1, from_slot);
+            G(I7{}, x1, from_slot, VmTag<EU, (UG < 3 ? UG : 3)>{});
         } else {
-            G(I6{}, x1, from_slot);
-            G(I7{}, x1, [&](int kk, int p) { return ub32[kk][p]; });
+            G(I6{}, x1, from_slot, VmNone{});
+            G(I7{}, x1, [&](int kk, int p) { return ub32[kk][p]; }, VmNone{});
         }
         STAMP(10);  // dense2 of the RSHMAG over cat[u', v'] (u' from HBM)
         if constexpr (CIN == 3) stage1_x0(x0);         // recomputed (3 MACs/channel): frees 32 registers across
@@ -776,13 +807,13 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel16(Sta
         STAMP(11);  // x0 recompute, R store, LN, slot
         f4 m1[NT][P];
         init_bias(m1, par + kParR1B * C + 64, q);
-        G(I8{}, m1, from_slot);
+        G(I8{}, m1, from_slot, VmTag<ER, 0>{});             // the R stores may stay in flight
         lrelu(m1);
         store_slot16(slot, m1, lane);
         STAMP(12);  // conv1 + lrelu + slot
         f4 t[NT][P];
         init_bias(t, par + kParR2B * C + 64, q);
-        G(I9{}, t, from_slot);
+        G(I9{}, t, from_slot, VmTag<ER, (UG < 3 ? UG : 3)>{});
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f4 s = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -831,15 +862,7 @@ template <int C> constexpr int ns_ht() { return C >= 256 ? 4 : 2; }
 
 template <int HT>
 __device__ __forceinline__ void ring_wait_barrier_ns(int after /* units issued after the awaited one */) {
-    // DMA instructions per unit and wave: 2 (HT = 4) or 1 (HT = 2)
-    if (after <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (HT == 4) {
-        if (after == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    } else {
-        if (after == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
+    ring_wait<(HT == 4 ? 2 : 1), 0>(after, false);       // DMA instructions per unit and wave: 2 (HT = 4) or 1 (HT = 2)
 }
 
 struct RingGemmNs {
@@ -897,7 +920,7 @@ __device__ __forceinline__ void chain_issue_ns(const RingChainNs &c, unsigned ch
     }
 }
 
-template <int NTL, int HT, int CI, int P, typename BL>
+template <int NTL, int HT, int CI, int P, typename VM, typename BL>
 __device__ __forceinline__ void chain_chunk_ns(f4 (&acc)[NTL][P], const RingChainNs &c, unsigned char *ring, int gu,
                                                int lane, int wave8, int hh, BL bload) {
     if constexpr (CI * HT < NTL) {
@@ -905,7 +928,7 @@ __device__ __forceinline__ void chain_chunk_ns(f4 (&acc)[NTL][P], const RingChai
         const int later = c.tot[1] + c.tot[2] + c.tot[3];
         for (int k = 0; k < ksn; ++k) {
             const int u = CI * ksn + k;
-            ring_wait_barrier_ns<HT>(c.tot[0] - 1 - u + later);
+            ring_wait<(HT == 4 ? 2 : 1), VM::e>(c.tot[0] - 1 - u + later, u + VM::used < 3);
             chain_issue_ns<HT>(c, ring, u + kNsRingSlots - 1, (gu + u + kNsRingSlots - 1) & (kNsRingSlots - 1), wave8, lane);
             HL a[HT], b[P];
             const unsigned char *sl =
@@ -930,14 +953,14 @@ __device__ __forceinline__ void chain_chunk_ns(f4 (&acc)[NTL][P], const RingChai
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[CI * HT + nt][p] = mfma16(a[nt].hi, b[p].hi, acc[CI * HT + nt][p]);
         }
-        chain_chunk_ns<NTL, HT, CI + 1, P>(acc, c, ring, gu, lane, wave8, hh, bload);
+        chain_chunk_ns<NTL, HT, CI + 1, P, VM>(acc, c, ring, gu, lane, wave8, hh, bload);
     }
 }
 
-template <int NTL, int HT, int P, typename BL>
+template <int NTL, int HT, int P, typename VM = VmNone, typename BL>
 __device__ __forceinline__ void gemm16_chain_ns(f4 (&acc)[NTL][P], const RingChainNs &c, int &gu, int lane, int wave8,
                                                 int hh, unsigned char *ring, BL bload) {
-    chain_chunk_ns<NTL, HT, 0, P>(acc, c, ring, gu, lane, wave8, hh, bload);
+    chain_chunk_ns<NTL, HT, 0, P, VM>(acc, c, ring, gu, lane, wave8, hh, bload);
     gu += c.tot[0];
 }
 
@@ -1027,6 +1050,7 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     }
 
     constexpr int NG = (MODE == 0) ? 6 : 10;
+    constexpr int EU = KSL * P * 2, ER = NTL * P, UG = (NTL / HT) * KS;      // ring-wait allowances (VmTag)
     const char *bb = reinterpret_cast<const char *>(blob);
     RingGemmNs seq[NG + 3];
     {
@@ -1092,10 +1116,10 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
         __syncthreads();
     }
 
-    auto G = [&](auto idx, auto &acc, auto bload) {
+    auto G = [&](auto idx, auto &acc, auto bload, auto vm) {
         constexpr int I = decltype(idx)::value;
         const RingChainNs c = make_chain_ns(seq[I], seq[I + 1], seq[I + 2], seq[I + 3], NG - I);
-        gemm16_chain_ns<NTL, HT, P>(acc, c, gu, lane, wave8, hh, ring, bload);
+        gemm16_chain_ns<NTL, HT, P, decltype(vm)>(acc, c, gu, lane, wave8, hh, ring, bload);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -1130,7 +1154,7 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     // ---- x0 = relu(conv0(X)) ----
     f4 x0[NTL][P];
     init_bias(x0, par + kParConv0B * C + 16 * nt0, q);
-    G(I0{}, x0, from_slot);
+    G(I0{}, x0, from_slot, VmNone{});
     relu(x0);
     {
         f4 h[NTL][P];
@@ -1139,7 +1163,7 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     }
     f4 z[NTL][P];
     init_bias(z, par + kParQ1B * C + 16 * nt0, q);
-    G(I1{}, z, from_slot);
+    G(I1{}, z, from_slot, VmNone{});
     gelu<false, (C == 128 && MODE == 1)>(z);
     {
         f4 h[NTL][P];
@@ -1148,12 +1172,12 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     }
     f4 ga[NTL][P];
     init_bias(ga, par + kParD1B * C + 16 * nt0, q);
-    G(I2{}, ga, from_slot);
+    G(I2{}, ga, from_slot, VmNone{});
     gelu<false, (C == 128 && MODE == 1)>(ga);
     {
         f4 gb[NTL][P];
         init_bias(gb, par + kParD1B * C + C + 16 * nt0, q);
-        G(I3{}, gb, from_slot);
+        G(I3{}, gb, from_slot, VmNone{});
         gelu<false, (C == 128 && MODE == 1)>(gb);
         {
             float mean[P], rstd[P];
@@ -1219,7 +1243,7 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
     to_slot(ga);                                        // (its barrier also ends the reads of bT)
     f4 o[NTL][P];
     init_bias(o, par + kParD2B * C + 16 * nt0, q);
-    G(I5{}, o, from_slot);
+    G(I5{}, o, from_slot, VmNone{});
 #pragma unroll
     for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
@@ -1241,7 +1265,7 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
         to_slot(o);
         f4 x1[NTL][P];
         init_bias(x1, par + kParQ2B * C + 64 + 16 * nt0, q);
-        G(I6{}, x1, from_slot);
+        G(I6{}, x1, from_slot, VmTag<EU, 0>{});                // the u' loads may stay in flight
         lds_barrier();
 #pragma unroll
         for (int kk = 0; kk < KSL; ++kk)
@@ -1250,7 +1274,7 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
                 slot[(((ks0 + kk) * P + p) * 2 + 0) * 64 + lane] = ub[kk][p].hi;
                 slot[(((ks0 + kk) * P + p) * 2 + 1) * 64 + lane] = ub[kk][p].lo;
             }
-        G(I7{}, x1, from_slot);
+        G(I7{}, x1, from_slot, VmTag<EU, (UG < 3 ? UG : 3)>{});
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
@@ -1262,12 +1286,12 @@ __global__ __launch_bounds__(512, (C >= 256 ? 2 : 4)) void stage_branch_kernel16
         to_slot(x1);
         f4 m1[NTL][P];
         init_bias(m1, par + kParR1B * C + 64 + 16 * nt0, q);
-        G(I8{}, m1, from_slot);
+        G(I8{}, m1, from_slot, VmTag<ER, 0>{});                // the R stores may stay in flight
         lrelu(m1);
         to_slot(m1);
         f4 t[NTL][P];
         init_bias(t, par + kParR2B * C + 64 + 16 * nt0, q);
-        G(I9{}, t, from_slot);
+        G(I9{}, t, from_slot, VmTag<ER, (UG < 3 ? UG : 3)>{});
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
             f4 ssum = {0.0f, 0.0f, 0.0f, 0.0f};
