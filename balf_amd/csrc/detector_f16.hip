@@ -1411,6 +1411,171 @@ __global__ __launch_bounds__(256, 2) void head_kernel16(HeadArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage-4 tail + detector head, second form (BALF_HEAD_NSPLIT): a workgroup = 64 pixels of the 1/8-resolution map.
+// head_kernel16 above gives every wave its own 16 pixels and lets it stream both weight matrices (256 KB + 80 KB of
+// split-f16 fragments) through L2 for them: 21 KB of weight traffic per pixel, waves parked or issue-stalled 91 % of the
+// time.  Here conv2 (256 -> 256) is split by OUTPUT channels: wave w computes row tiles 4w .. 4w+3 for all four pixel
+// tiles, so the workgroup reads conv2 once (256 KB per 64 pixels instead of per 16) and every 8 KB of weights feeds
+// 48 MFMAs.  x2 = t*s + r is staged once as shared B fragments in LDS (64 KB), the conv2 output goes back through the
+// same buffer (wave w owns K-steps 2w, 2w+1 of it), the 65-way head Linear + BatchNorm + softmax + pixel shuffle
+// stay per pixel tile.  Reference: Down.forward tail, mlp_ma_decoder.py:241-244; DetectorHead, decoder.py:16-30.
+// ------------------------------------------------------------------------------------------------
+#ifndef BALF_HEAD_NSPLIT
+#define BALF_HEAD_NSPLIT 1
+#endif
+__global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
+    constexpr int C = 256, KS = 8, HT = kHeadNPad / 16;
+    __shared__ __attribute__((aligned(16))) h8 xs[4 * KS * 2 * 64];          // [tile][K-step][hi|lo][lane]: 64 KiB
+    const int lane = threadIdx.x & 63, q = lane >> 4, li = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float *blob = A.blob;
+    const long hw = (long)A.h * A.w;
+    const long pixel = ((long)blockIdx.x * 4 + wave) * 16 + li;               // this wave's own pixel tile
+    const int n = (int)(pixel / hw);
+    const long o = pixel - (long)n * hw;
+    const int i = (int)(o / A.w), j = (int)(o - (long)i * A.w);
+
+    // ---- x2 = t * s + r of the wave's 16 pixels -> shared B fragments ----
+    {
+        h8 *slot = xs + wave * (KS * 2 * 64);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                                 // two batches of 4 K-steps: 16 loads in flight
+            f4 tv[4][2], rv[4][2];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int c0 = 32 * (4 * half + k4) + 4 * q;
+                tv[k4][0] = ldg4(A.T + pixel * C + c0);      tv[k4][1] = ldg4(A.T + pixel * C + c0 + 16);
+                rv[k4][0] = ldg4(A.R + pixel * C + c0);      rv[k4][1] = ldg4(A.R + pixel * C + c0 + 16);
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int kk = 4 * half + k4, c0 = 32 * kk + 4 * q;
+                const f4 v0 = tv[k4][0] * ldg4(A.scale + (long)n * C + c0) + rv[k4][0];
+                const f4 v1 = tv[k4][1] * ldg4(A.scale + (long)n * C + c0 + 16) + rv[k4][1];
+                const HL v = split8(v0, v1);
+                slot[(kk * 2 + 0) * 64 + lane] = v.hi;
+                slot[(kk * 2 + 1) * 64 + lane] = v.lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2: row tiles 4w .. 4w+3 x four pixel tiles; weight fragments one K-step ahead in registers ----
+    f4 f[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f4 b = ldg4(blob + A.off.conv2_b + 16 * (4 * wave + t) + 4 * q);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) f[t][p] = b;
+    }
+    {
+        const char *wb = reinterpret_cast<const char *>(blob + A.off.conv2_w) + ((size_t)(4 * wave) * KS) * 2048 + lane * 16;
+        auto wload = [&](HL (&a)[4], int kk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const char *p = wb + ((size_t)t * KS + kk) * 2048;
+                a[t].hi = *reinterpret_cast<const h8 *>(p);
+                a[t].lo = *reinterpret_cast<const h8 *>(p + 1024);
+            }
+        };
+        auto compute = [&](const HL (&a)[4], int kk) {
+            HL b[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                b[p].hi = xs[(p * KS + kk) * 2 * 64 + lane];
+                b[p].lo = xs[(p * KS + kk) * 2 * 64 + 64 + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) f[t][p] = mfma16(a[t].lo, b[p].hi, f[t][p]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) f[t][p] = mfma16(a[t].hi, b[p].lo, f[t][p]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) f[t][p] = mfma16(a[t].hi, b[p].hi, f[t][p]);
+        };
+        HL a0[4], a1[4];
+        wload(a0, 0);
+        for (int kk = 0; kk < KS; kk += 2) {
+            wload(a1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a0, kk);
+            __builtin_amdgcn_sched_barrier(0);
+            wload(a0, kk + 2 < KS ? kk + 2 : kk);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();                                  // everyone is done reading x2: the buffer takes the conv2 output
+    // relu -> B fragments of the head Linear: this wave's 4 row tiles are K-steps 2w, 2w+1 of every pixel tile
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            f4 v0 = f[2 * s2][p], v1 = f[2 * s2 + 1][p];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v0[r] = max0(v0[r]); v1[r] = max0(v1[r]); }
+            const HL v = split8(v0, v1);
+            xs[(p * KS + 2 * wave + s2) * 2 * 64 + lane] = v.hi;
+            xs[(p * KS + 2 * wave + s2) * 2 * 64 + 64 + lane] = v.lo;
+        }
+    __syncthreads();
+
+    // ---- head Linear 256 -> 65 (padded to 80) on the wave's own pixel tile, BatchNorm(eval), softmax, pixel shuffle ----
+    f4 z[HT][1];
+    init_bias(z, blob + A.head_b, q);
+    {
+        const h8 *slot = xs + wave * (KS * 2 * 64);
+        gemm16<HT, 1>(z, blob + A.head_w, 0, KS, 0, KS, lane, [&](int kk, int) {
+            HL v;
+            v.hi = slot[(kk * 2 + 0) * 64 + lane];
+            v.lo = slot[(kk * 2 + 1) * 64 + lane];
+            return v;
+        });
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+        const f4 al = ldg4(blob + A.head_alpha + 16 * t + 4 * q), be = ldg4(blob + A.head_beta + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * t + 4 * q + r;
+            z[t][0][r] = z[t][0][r] * al[r] + be[r];
+            if (c < kHeadN) {
+                mx = fmaxf(mx, z[t][0][r]);
+                if (A.logits) A.logits[((long)n * kHeadN + c) * hw + o] = z[t][0][r];
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * t + 4 * q + r;
+            const float e = (c < kHeadN) ? expf(z[t][0][r] - mx) : 0.0f;
+            z[t][0][r] = e;
+            sum += e;
+        }
+    sum = quarter_allreduce(sum);
+    const float inv = 1.0f / sum;
+    const int Wp = 8 * A.w;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f4 pr = z[t][0] * inv;
+        float *dst = A.prob + ((long)n * 8 * A.h + 8 * i + 2 * t + (q >> 1)) * Wp + 8 * j + 4 * (q & 1);
+        *reinterpret_cast<f4 *>(dst) = pr;
+    }
+}
+
 #ifndef BALF_S1_WAVE
 #define BALF_S1_WAVE 1      // stage 1: persistent wave-owns-group kernels (stage1_f16.h); 0 = generic stage kernels
 #endif
@@ -1534,7 +1699,8 @@ int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
                     logits_dev ? logits_dev + (size_t)b0 * kHeadN * h8 * w8 : nullptr,
                     prob_dev + (size_t)b0 * Hp * Wp};
         BALF_PROF(15, st,
-                  hipLaunchKernelGGL(head_kernel16, dim3((unsigned)((long)nb * h8 * w8 / 64)), dim3(256), 0, st, ha));
+                  hipLaunchKernelGGL(BALF_HEAD_NSPLIT ? head_kernel16_ns : head_kernel16,
+                                     dim3((unsigned)((long)nb * h8 * w8 / 64)), dim3(256), 0, st, ha));
         BALF_LAUNCH_CHECK();
     }
     return BALF_OK;

@@ -1,5 +1,4 @@
 python tools/check_f16.py 2>&1 | grep -v amdgpu.ids
-tools/run_variants.sh gpurun_out/r2j fp16 novx | cut -c1-330
+tools/run_variants.sh gpurun_out/r2k fp16 oldhead | cut -c1-330
 timeout 1200 python -m pytest tests/test_forward_gpu.py tests/test_configs_gpu.py -x -q -m gpu 2>&1 | tail -3
-python tools/soak.py 100 16 1088 1920 2>&1 | tail -1
-python tools/soak.py 200 4 512 640 2>&1 | tail -1
+python tools/soak.py 60 16 1088 1920 2>&1 | tail -1
