@@ -1580,6 +1580,10 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
 #define BALF_S1_WAVE 1      // stage 1: persistent wave-owns-group kernels (stage1_f16.h); 0 = generic stage kernels
 #endif
 #include "stage1_f16.h"
+#ifndef BALF_CS_MIN_C
+#define BALF_CS_MIN_C 128   // stages with C >= this run the channel-split kernels (stage_cs_f16.h); 1024 = ring kernels everywhere
+#endif
+#include "stage_cs_f16.h"
 
 template <int C, int CIN>
 int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
@@ -1618,6 +1622,21 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
         };
         BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(g0, dim3(blocks(s1_waves<0>())), dim3(s1_waves<0>() * 64), l0, st, a));
         BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(g1, dim3(blocks(s1_waves<1>())), dim3(s1_waves<1>() * 64), l1, st, a));
+    } else if constexpr (C >= BALF_CS_MIN_C && C >= 128) {
+        // channel-split kernels: one workgroup of C/32 waves per token group, no weight ring
+        auto c0k = stage_cs_kernel16<C, CIN, 0>;
+        auto c1k = stage_cs_kernel16<C, CIN, 1>;
+        constexpr int clds = cs_lds_bytes<C>();
+        static_assert(clds <= 160 * 1024, "channel-split LDS image");
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(c0k), hipFuncAttributeMaxDynamicSharedMemorySize, clds) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(c1k), hipFuncAttributeMaxDynamicSharedMemorySize, clds) !=
+                hipSuccess)
+            return BALF_ERR_LAUNCH;
+        per_img = (H / 8) * (W / 8);                       // one partial-sum row per token group
+        const unsigned groups = (unsigned)((long)B * per_img);
+        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(c0k, dim3(groups), dim3(cs_waves<C>() * 64), clds, st, a));
+        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(c1k, dim3(groups), dim3(cs_waves<C>() * 64), clds, st, a));
     } else if constexpr ((C == 256 && BALF_NS256 != 0) || (C == 128 && BALF_NS128 != 0) || (C == 64 && BALF_NS64 != 0)) {
         constexpr int nlds = ns_lds_bytes<C>();
         static_assert(nlds <= (C >= 256 ? 160 : 80) * 1024, "N-split LDS image");

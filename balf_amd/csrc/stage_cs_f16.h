@@ -1,0 +1,403 @@
+// Channel-split stage kernels for C >= 128 (split-f16 path).  Included by detector_f16.hip inside balf::{anonymous}.
+//
+// Reference: Down.forward / ResidualSplitHeadMultiAxisGmlpLayer / {Grid,Block}GmlpLayer / RCAB of
+// /root/reference/balf/model/mlp_ma_decoder.py:25-149,173-244 at C = 128 / 256.
+//
+// The weight-ring kernels above share every weight tile through LDS and pay for it with one workgroup barrier per ring
+// unit (86 / 157 per token group at C = 256), waves parked 43-47 % of the time and the LDS array busy 36-46 %.  Here the
+// workgroup splits every Linear by OUTPUT CHANNELS instead: wave w (of C/32) owns channels 32w .. 32w+31 of all 64
+// tokens of one token group -- a 2 x 4 register tile (two 16-channel row tiles x four 16-pixel tiles), the shapes of the
+// stage-1 kernel.  Consequences:
+//   * a weight fragment is needed by exactly ONE wave: it comes straight from L2 into double-buffered registers (two
+//     K-steps ahead of the MFMAs), there is no ring, no LDS copy of the weights and no barrier per weight tile;
+//   * the 64x64 token mix of a channel is wave-local (transposed tile in wave-private LDS, as in stage 1);
+//   * what the waves exchange is the ACTIVATION: a Linear's input is the B operand of all waves, so every wave writes its
+//     32 channels as one K-step of split-f16 fragments into a shared buffer (64 KB at C = 256) and a barrier publishes
+//     it; LayerNorm needs the statistics of all channels of a pixel, exchanged through a small LDS table.  7 barriers per
+//     token group in the grid branch, 13 in the block branch.
+// Token t = 8 ty + tx of the group sits in MFMA column li of pixel tile p with t = 4 li + p (see stage1_f16.h).
+#pragma once
+
+template <int C> constexpr int cs_waves() { return C / 32; }
+template <int C> constexpr int cs_bx_bytes() { return (C / 32) * 4 * 2048; }          // [K-step][tile][hi|lo][64 x 16 B]
+template <int C> constexpr int cs_bt_bytes() {                                          // token tiles / u' staging
+    constexpr int bt = cs_waves<C>() * kS1BtBytes, bu = cs_bx_bytes<C>();
+    return bt > bu ? bt : bu;
+}
+template <int C> constexpr bool cs_mix_in_lds() { return C >= 256; }                    // C = 128: two workgroups per CU instead
+template <int C> constexpr int cs_lds_bytes() {
+    return cs_bx_bytes<C>() + cs_bt_bytes<C>() + (cs_mix_in_lds<C>() ? 8 * 2048 : 0) + cs_waves<C>() * 4 * 16 * 8;
+}
+
+// Weight fragments of one K-step pair of this wave's two row tiles (32 registers) and a Linear's bias slice.
+struct CsW {
+    HL a[2][2];       // [K-step of the pair][row tile]
+};
+
+// weight tile (t, ks) of this wave at wbase + (t * kstot + ks) * 2048 (+ 1024: lo), straight from L2
+__device__ __forceinline__ void cs_wload(CsW &w, const char *wbase, int kstot, int ks) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const char *p = wbase + ((size_t)t * kstot + ks + s) * 2048;
+            w.a[s][t].hi = *reinterpret_cast<const h8 *>(p);
+            w.a[s][t].lo = *reinterpret_cast<const h8 *>(p + 1024);
+        }
+}
+
+// acc[t][p] += W(row tiles t = 0, 1 of this wave) . B over KSN K-steps.  `first` holds the fragments of K-steps 0, 1,
+// requested by the caller BEFORE the epilogue / barriers in front of this Linear (an L2 round trip at the head of every
+// Linear is otherwise exposed: the workgroup's waves move in step, nothing else covers it); inside the loop the next
+// pair is requested while the current one is consumed.  bsrc(ks) -> the shared B fragments of K-step ks, [p][hi|lo][lane].
+template <int KSN, typename BS>
+__device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, const char *wbase, int kstot, BS bsrc, int lane) {
+    static_assert(KSN % 2 == 0, "K-steps come in pairs");
+    auto compute = [&](const CsW &w, int ks) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const h8 *bk = bsrc(ks + s);
+            HL b[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                b[p].hi = bk[(p * 2 + 0) * 64 + lane];
+                b[p].lo = bk[(p * 2 + 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[t][p] = mfma16(w.a[s][t].lo, b[p].hi, acc[t][p]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[t][p] = mfma16(w.a[s][t].hi, b[p].lo, acc[t][p]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[t][p] = mfma16(w.a[s][t].hi, b[p].hi, acc[t][p]);
+        }
+    };
+    if constexpr (KSN == 2) {
+        compute(first, 0);
+    } else {
+        static_assert(KSN % 4 == 0, "K-step pairs come in pairs");
+        CsW a0 = first, a1;
+        for (int ks = 0; ks < KSN; ks += 4) {
+            cs_wload(a1, wbase, kstot, ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a0, ks);
+            __builtin_amdgcn_sched_barrier(0);
+            cs_wload(a0, wbase, kstot, ks + 4 < KSN ? ks + 4 : ks);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a1, ks + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int C, int CIN, int MODE>
+__global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(StageArgs A) {
+    constexpr int NW = cs_waves<C>(), KS = C / 32, KI = CIN / 32, NT = C / 16, P = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    h8 *bx = reinterpret_cast<h8 *>(smem_raw);                                            // shared B fragments
+    unsigned char *btr = smem_raw + cs_bx_bytes<C>();                                      // token tiles, later u'
+    h8 *bu = reinterpret_cast<h8 *>(btr);
+    const unsigned char *wmix_l = btr + cs_bt_bytes<C>();                                  // (C = 256) re-ordered Wmix
+    float *stats = reinterpret_cast<float *>(smem_raw + cs_bx_bytes<C>() + cs_bt_bytes<C>() +
+                                             (cs_mix_in_lds<C>() ? 8 * 2048 : 0));         // [NW][4][16] (sum, sumsq)
+    const int lane = threadIdx.x & 63, q = lane >> 4, li = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    _Float16 *bT = reinterpret_cast<_Float16 *>(btr + wave * kS1BtBytes);
+    const float *blob = A.blob;
+    const StageOff &S = A.off;
+    const BranchOff &Br = S.br[MODE];
+    const char *bb = reinterpret_cast<const char *>(blob);
+    const int c0 = 32 * wave;                                                              // this wave's first channel
+
+    const int H = A.H, W = A.W, fh = H / 8, fw = W / 8;
+    const int per_img = fh * fw;
+    // XCD-aware group order (speed only), as in the ring kernels
+    const int nwg = gridDim.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xl = blockIdx.x & 7, xj = blockIdx.x >> 3;
+    const int item = (xl < xr ? xl * (xq + 1) : xr * (xq + 1) + (xl - xr) * xq) + xj;
+    const int n = item / per_img, rem = item - n * per_img;
+    const int gy = rem / fw, gx = rem - gy * fw;
+    const int ty = li >> 1, tx0 = 4 * (li & 1);
+    int y, xl0;
+    if (MODE == 0) { y = ty * fh + gy; xl0 = tx0 * fw + gx; }
+    else           { y = 8 * gy + ty;  xl0 = 8 * gx + tx0; }
+    const int pstep = (MODE == 0) ? fw : 1;
+    const long pix0 = ((long)n * H + y) * W + xl0;
+
+    auto barrier = [&]() { lds_barrier(); };                 // lgkmcnt(0) + s_barrier: never drains loads or stores
+
+    // ---- stage input -> shared B fragments (KI x 4 fragments, two per wave); (C = 256) the re-ordered mixing matrix ----
+    {
+        static_assert(KI * 4 == 2 * NW, "two input fragments per wave");
+        HL xin[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int fi = 2 * wave + f, kk = fi >> 2, p = fi & 3;
+            xin[f] = load_frag_px(A.X, pix0 + p * pstep, CIN, kk, q);
+        }
+        if constexpr (cs_mix_in_lds<C>()) {
+            for (int i = threadIdx.x; i < 8 * 2 * 64; i += NW * 64) {
+                const int l = i & 63, part = (i >> 6) & 1, tile = i >> 7, pt = tile >> 1, ks = tile & 1;
+                const int g = 4 * (l & 15) + pt;
+                const int stile = (g >> 4) * 2 + ks, sl = (g & 15) + 16 * (l >> 4);
+                *reinterpret_cast<uint4 *>(const_cast<unsigned char *>(wmix_l) + tile * 2048 + part * 1024 + l * 16) =
+                    *reinterpret_cast<const uint4 *>(bb + (size_t)Br.mix_w * 4 + stile * 2048 + part * 1024 + sl * 16);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int fi = 2 * wave + f;
+            bx[(fi * 2 + 0) * 64 + lane] = xin[f].hi;
+            bx[(fi * 2 + 1) * 64 + lane] = xin[f].lo;
+        }
+    }
+    barrier();
+
+    struct Bias { f4 b[2]; };
+    auto bias_load = [&](int off_floats) {                    // this wave's 32 channels of a bias vector (requested early)
+        Bias r;
+        r.b[0] = ldg4(blob + off_floats + c0 + 4 * q);
+        r.b[1] = ldg4(blob + off_floats + c0 + 16 + 4 * q);
+        return r;
+    };
+    auto bias_fill = [&](f4 (&t)[2][4], const Bias &b) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int p = 0; p < P; ++p) t[nt][p] = b.b[nt];
+    };
+    auto wptr = [&](int w_off_floats, int row_tile0, int kstot, int ks0) {      // first weight tile of this wave
+        return bb + (size_t)w_off_floats * 4 + ((size_t)(row_tile0 + 2 * wave) * kstot + ks0) * 2048 + lane * 16;
+    };
+    auto from_bx = [&](int ks) { return bx + ks * (4 * 2 * 64); };
+    // per-pixel LayerNorm statistics over ALL channels: this wave's partial sums through LDS (one barrier)
+    auto ln_stats_all = [&](const f4 (&x)[2][4], float (&rstd)[P], float (&shift)[P]) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float s = 0.0f, ss = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s += x[nt][p][r]; ss = fmaf(x[nt][p][r], x[nt][p][r], ss); }
+            quarter_allreduce2(s, ss);
+            if (q == 0) *reinterpret_cast<float2 *>(stats + ((wave * 4 + p) * 16 + li) * 2) = make_float2(s, ss);
+        }
+        barrier();
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float s = 0.0f, ss = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float2 v = *reinterpret_cast<const float2 *>(stats + ((w * 4 + p) * 16 + li) * 2);
+                s += v.x; ss += v.y;
+            }
+            const float mean = s * (1.0f / C);
+            const float var = fmaf(ss, 1.0f / C, -mean * mean);
+            rstd[p] = __builtin_amdgcn_rsqf(max0(var) + kLnEps);
+            shift[p] = -mean * rstd[p];
+        }
+    };
+    // publish this wave's 32 channels as K-step `wave` of the shared B fragments (callers put the barriers)
+    auto publish = [&](h8 *dst, const f4 (&t)[2][4]) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const HL v = split8(t[0][p], t[1][p]);
+            dst[((wave * 4 + p) * 2 + 0) * 64 + lane] = v.hi;
+            dst[((wave * 4 + p) * 2 + 1) * 64 + lane] = v.lo;
+        }
+    };
+    auto ln_publish = [&](const f4 (&x)[2][4]) {               // (x - mean) * rstd -> shared B (affine folded into the weights)
+        float rstd[P], shift[P];
+        ln_stats_all(x, rstd, shift);                          // its barrier also says: everyone is done reading bx
+        f4 yv[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[nt][p][r] = fmaf(x[nt][p][r], rstd[p], shift[p]);
+        publish(bx, yv);
+        barrier();
+    };
+
+    // Every Linear's first weight fragments and bias are requested before the epilogue / barriers in front of it.
+    // ---- x0 = relu(conv0(X)) ----
+    const char *w_c0 = wptr(S.conv0_w, 0, KI, 0), *w_q1 = wptr(S.q1_w, MODE * NT, KS, 0);
+    const char *w_d1a = wptr(Br.d1_w, 0, KS, 0), *w_d1b = wptr(Br.d1_w, NT, KS, 0), *w_d2 = wptr(Br.d2_w, 0, KS, 0);
+    f4 x0[2][4];
+    {
+        CsW w;
+        cs_wload(w, w_c0, KI, 0);
+        bias_fill(x0, bias_load(S.conv0_b));
+        cs_linear<KI>(x0, w, w_c0, KI, from_bx, lane);
+    }
+    CsW wn;                                                    // the NEXT Linear's first fragments
+    cs_wload(wn, w_q1, KS, 0);
+    Bias bn = bias_load(S.q1_b + MODE * C);
+    relu(x0);
+    ln_publish(x0);
+    // ---- z = GELU(dense1 half) ----
+    f4 z[2][4];
+    bias_fill(z, bn);
+    cs_linear<KS>(z, wn, w_q1, KS, from_bx, lane);
+    cs_wload(wn, w_d1a, KS, 0);
+    bn = bias_load(Br.d1_b);
+    gelu<false>(z);
+    ln_publish(z);
+    // ---- branch dense1: a half, b half (same B operand) ----
+    f4 ga[2][4];
+    bias_fill(ga, bn);
+    cs_linear<KS>(ga, wn, w_d1a, KS, from_bx, lane);
+    cs_wload(wn, w_d1b, KS, 0);
+    bn = bias_load(Br.d1_b + C);
+    gelu<false>(ga);
+    {
+        f4 gb[2][4];
+        bias_fill(gb, bn);
+        cs_linear<KS>(gb, wn, w_d1b, KS, from_bx, lane);
+        cs_wload(wn, w_d2, KS, 0);                             // dense2's first fragments travel through the token mix
+        bn = bias_load(Br.d2_b);
+        gelu<false>(gb);
+        float rstd[P], shift[P];
+        ln_stats_all(gb, rstd, shift);                         // gating LayerNorm (affine) over all C channels
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f4 gg = ldg4(blob + Br.gln_g + c0 + 16 * nt + 4 * q), be = ldg4(blob + Br.gln_b + c0 + 16 * nt + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) v[p] = fmaf(fmaf(gb[nt][p][r], rstd[p], shift[p]), gg[r], be[r]);
+                h2 h01, l01, h23, l23;
+                split_pair(v[0], v[1], h01, l01);
+                split_pair(v[2], v[3], h23, l23);
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                _Float16 *row = bT + (16 * nt + 4 * q + r) * kS1Pitch + 4 * li;
+                *reinterpret_cast<h4 *>(row) = h4{h01[0], h01[1], h23[0], h23[1]};
+                *reinterpret_cast<h4 *>(row + kS1C * kS1Pitch) = h4{l01[0], l01[1], l23[0], l23[1]};
+            }
+        }
+    }
+    {   // token mix of this wave's 32 channels (wave-local) and the gate
+        HL a[2][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const _Float16 *row = bT + (16 * ct + li) * kS1Pitch + 32 * kk + 8 * q;
+                a[ct][kk].hi = *reinterpret_cast<const h8 *>(row);
+                a[ct][kk].lo = *reinterpret_cast<const h8 *>(row + kS1C * kS1Pitch);
+            }
+        const f4 mbv = ldg4(blob + Br.mix_b + 4 * li);
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            HL w0, w1;
+            if constexpr (cs_mix_in_lds<C>()) {
+                const unsigned char *wl = wmix_l + lane * 16;
+                w0.hi = *reinterpret_cast<const h8 *>(wl + (pt * 2 + 0) * 2048);
+                w0.lo = *reinterpret_cast<const h8 *>(wl + (pt * 2 + 0) * 2048 + 1024);
+                w1.hi = *reinterpret_cast<const h8 *>(wl + (pt * 2 + 1) * 2048);
+                w1.lo = *reinterpret_cast<const h8 *>(wl + (pt * 2 + 1) * 2048 + 1024);
+            } else {                                            // natural fragments in the blob: column li of tile pt = token 4 li + pt
+                const int g = 4 * li + pt;
+                const char *wg = bb + (size_t)Br.mix_w * 4 + ((g & 15) + 16 * q) * 16;
+                w0.hi = *reinterpret_cast<const h8 *>(wg + ((g >> 4) * 2 + 0) * 2048);
+                w0.lo = *reinterpret_cast<const h8 *>(wg + ((g >> 4) * 2 + 0) * 2048 + 1024);
+                w1.hi = *reinterpret_cast<const h8 *>(wg + ((g >> 4) * 2 + 1) * 2048);
+                w1.lo = *reinterpret_cast<const h8 *>(wg + ((g >> 4) * 2 + 1) * 2048 + 1024);
+            }
+            const float mb1 = mbv[pt] + 1.0f;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                f4 m = {mb1, mb1, mb1, mb1};
+                m = mfma16x3(a[ct][0], w0, m);
+                m = mfma16x3(a[ct][1], w1, m);
+                ga[ct][pt] *= m;
+            }
+        }
+    }
+    publish(bx, ga);                                           // every wave is past the gating-LN barrier: bx is free
+    barrier();
+    // ---- branch dense2 + residual ----
+    f4 o[2][4];
+    bias_fill(o, bn);
+    cs_linear<KS>(o, wn, w_d2, KS, from_bx, lane);
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            f4 o0 = o[0][p] + z[0][p], o1 = o[1][p] + z[1][p];
+            store_frag_px(A.U, pix0 + p * pstep, C, wave, q, split8(o0, o1));
+        }
+    } else {
+        const char *w_q2 = wptr(S.q2_w, 0, 2 * KS, 0), *w_r1 = wptr(S.r1_w, 0, KS, 0), *w_r2 = wptr(S.r2_w, 0, KS, 0);
+        // this wave's four u' fragments (of KS x 4): written by the grid kernel just before, served from L2 / the
+        // Infinity Cache; requested here (not before dense2: 32 more live registers there mean spills)
+        static_assert(KS * 4 == 4 * NW, "four u' fragments per wave");
+        HL ub[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int fi = 4 * wave + f, kk = fi >> 2, p = fi & 3;
+            ub[f] = load_frag_px(A.U, pix0 + p * pstep, C, kk, q);
+        }
+        cs_wload(wn, w_q2, 2 * KS, 0);
+        bn = bias_load(S.q2_b);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int p = 0; p < P; ++p) o[nt][p] += z[nt][p];
+        barrier();                                             // everyone is done with dense2's B operand (and with the token tiles)
+        publish(bx, o);                                        // v'
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {                          // u' -> the token-tile region, as shared B fragments
+            const int fi = 4 * wave + f;
+            bu[(fi * 2 + 0) * 64 + lane] = ub[f].hi;
+            bu[(fi * 2 + 1) * 64 + lane] = ub[f].lo;
+        }
+        barrier();
+        // RSHMAG.dense2 over cat[u', v']: K-steps 0 .. KS-1 from the u' fragments, KS .. 2KS-1 from v'
+        f4 x1[2][4];
+        bias_fill(x1, bn);
+        cs_linear<2 * KS>(x1, wn, w_q2, 2 * KS,
+                          [&](int ks) { return ks < KS ? bu + ks * (4 * 2 * 64) : bx + (ks - KS) * (4 * 2 * 64); }, lane);
+        cs_wload(wn, w_r1, KS, 0);
+        bn = bias_load(S.r1_b);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                x1[nt][p] += x0[nt][p];
+                *reinterpret_cast<f4 *>(A.R + (pix0 + p * pstep) * C + c0 + 16 * nt + 4 * q) = x1[nt][p] + x0[nt][p];
+            }
+        ln_publish(x1);
+        f4 m1[2][4];
+        bias_fill(m1, bn);
+        cs_linear<KS>(m1, wn, w_r1, KS, from_bx, lane);
+        cs_wload(wn, w_r2, KS, 0);
+        bn = bias_load(S.r2_b);
+        lrelu(m1);
+        barrier();                                             // everyone is done with conv1's B operand
+        publish(bx, m1);
+        barrier();
+        f4 t[2][4];
+        bias_fill(t, bn);
+        cs_linear<KS>(t, wn, w_r2, KS, from_bx, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f4 s = t[nt][0];
+            *reinterpret_cast<f4 *>(A.T + pix0 * C + c0 + 16 * nt + 4 * q) = t[nt][0];
+#pragma unroll
+            for (int p = 1; p < P; ++p) {
+                *reinterpret_cast<f4 *>(A.T + (pix0 + p * pstep) * C + c0 + 16 * nt + 4 * q) = t[nt][p];
+                s += t[nt][p];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = row_ror_add<1>(row_ror_add<2>(row_ror_add<4>(row_ror_add<8>(s[r]))));
+            if (li == 0) *reinterpret_cast<f4 *>(A.partial + (long)item * C + c0 + 16 * nt + 4 * q) = s;
+        }
+    }
+}
