@@ -1581,7 +1581,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
 #endif
 #include "stage1_f16.h"
 #ifndef BALF_CS_MIN_C
-#define BALF_CS_MIN_C 128   // stages with C >= this run the channel-split kernels (stage_cs_f16.h); 1024 = ring kernels everywhere
+#define BALF_CS_MIN_C 64    // stages with C >= this run the channel-split kernels (stage_cs_f16.h); 1024 = ring kernels everywhere
 #endif
 #include "stage_cs_f16.h"
 
@@ -1622,7 +1622,7 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
         };
         BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(g0, dim3(blocks(s1_waves<0>())), dim3(s1_waves<0>() * 64), l0, st, a));
         BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(g1, dim3(blocks(s1_waves<1>())), dim3(s1_waves<1>() * 64), l1, st, a));
-    } else if constexpr (C >= BALF_CS_MIN_C && C >= 128) {
+    } else if constexpr (C >= BALF_CS_MIN_C && C >= 64) {
         // channel-split kernels: one workgroup of C/32 waves per token group, no weight ring
         auto c0k = stage_cs_kernel16<C, CIN, 0>;
         auto c1k = stage_cs_kernel16<C, CIN, 1>;

@@ -24,7 +24,7 @@ template <int C> constexpr int cs_bt_bytes() {                                  
     constexpr int bt = cs_waves<C>() * kS1BtBytes, bu = cs_bx_bytes<C>();
     return bt > bu ? bt : bu;
 }
-template <int C> constexpr bool cs_mix_in_lds() { return C >= 256; }                    // C = 128: two workgroups per CU instead
+template <int C> constexpr bool cs_mix_in_lds() { return C >= 256; }                    // C <= 128: more workgroups per CU instead
 template <int C> constexpr int cs_lds_bytes() {
     return cs_bx_bytes<C>() + cs_bt_bytes<C>() + (cs_mix_in_lds<C>() ? 8 * 2048 : 0) + cs_waves<C>() * 4 * 16 * 8;
 }
@@ -35,9 +35,10 @@ struct CsW {
 };
 
 // weight tile (t, ks) of this wave at wbase + (t * kstot + ks) * 2048 (+ 1024: lo), straight from L2
+template <int NSTEP = 2>
 __device__ __forceinline__ void cs_wload(CsW &w, const char *wbase, int kstot, int ks) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const char *p = wbase + ((size_t)t * kstot + ks + s) * 2048;
@@ -52,10 +53,10 @@ __device__ __forceinline__ void cs_wload(CsW &w, const char *wbase, int kstot, i
 // pair is requested while the current one is consumed.  bsrc(ks) -> the shared B fragments of K-step ks, [p][hi|lo][lane].
 template <int KSN, typename BS>
 __device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, const char *wbase, int kstot, BS bsrc, int lane) {
-    static_assert(KSN % 2 == 0, "K-steps come in pairs");
+    static_assert(KSN == 1 || KSN % 2 == 0, "K-steps come in pairs (or a single one: conv0 of stage 2)");
     auto compute = [&](const CsW &w, int ks) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < (KSN == 1 ? 1 : 2); ++s) {
             const h8 *bk = bsrc(ks + s);
             HL b[4];
 #pragma unroll
@@ -77,7 +78,7 @@ __device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, con
                 for (int p = 0; p < 4; ++p) acc[t][p] = mfma16(w.a[s][t].hi, b[p].hi, acc[t][p]);
         }
     };
-    if constexpr (KSN == 2) {
+    if constexpr (KSN <= 2) {
         compute(first, 0);
     } else {
         static_assert(KSN % 4 == 0, "K-step pairs come in pairs");
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
 
     // ---- stage input -> shared B fragments (KI x 4 fragments, two per wave); (C = 256) the re-ordered mixing matrix ----
     {
-        static_assert(KI * 4 == 2 * NW, "two input fragments per wave");
+        static_assert(KI * 4 == 2 * NW, "two input fragments per wave");           // holds for C = 64, 128, 256
         HL xin[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
     f4 x0[2][4];
     {
         CsW w;
-        cs_wload(w, w_c0, KI, 0);
+        cs_wload<(KI == 1 ? 1 : 2)>(w, w_c0, KI, 0);
         bias_fill(x0, bias_load(S.conv0_b));
         cs_linear<KI>(x0, w, w_c0, KI, from_bx, lane);
     }
