@@ -29,6 +29,9 @@ template <int C> constexpr int cs_lds_bytes() {
     return cs_bx_bytes<C>() + cs_bt_bytes<C>() + (cs_mix_in_lds<C>() ? 8 * 2048 : 0) + cs_waves<C>() * 4 * 16 * 8;
 }
 
+#ifndef BALF_CS_SCHED
+#define BALF_CS_SCHED 1      // 1: a scheduling fence only behind the weight requests (measured best; 0: none, 2: also behind the MFMAs)
+#endif
 // Weight fragments of one K-step pair of this wave's two row tiles (32 registers) and a Linear's bias slice.
 struct CsW {
     HL a[2][2];       // [K-step of the pair][row tile]
@@ -83,15 +86,16 @@ __device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, con
     } else {
         static_assert(KSN % 4 == 0, "K-step pairs come in pairs");
         CsW a0 = first, a1;
+#pragma unroll
         for (int ks = 0; ks < KSN; ks += 4) {
             cs_wload(a1, wbase, kstot, ks + 2);
-            __builtin_amdgcn_sched_barrier(0);
+            if (BALF_CS_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);     // the requests go out before the MFMAs they hide behind
             compute(a0, ks);
-            __builtin_amdgcn_sched_barrier(0);
-            cs_wload(a0, wbase, kstot, ks + 4 < KSN ? ks + 4 : ks);
-            __builtin_amdgcn_sched_barrier(0);
+            if (BALF_CS_SCHED >= 2) __builtin_amdgcn_sched_barrier(0);
+            if (ks + 4 < KSN) cs_wload(a0, wbase, kstot, ks + 4);
+            if (BALF_CS_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
             compute(a1, ks + 2);
-            __builtin_amdgcn_sched_barrier(0);
+            if (BALF_CS_SCHED >= 2) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
