@@ -170,7 +170,10 @@ __device__ __forceinline__ void lrelu(f4 (&t)[NT][P]) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = t[nt][p][r];
-                t[nt][p][r] = v > 0.0f ? v : 0.2f * v;
+                // = v > 0 ? v : 0.2 v (slope < 1) in two instructions: the compiler's fmaxf first canonicalises v
+                // (a third instruction); m is an arithmetic result and v has been read by the multiply before
+                const float m = 0.2f * v;
+                asm("v_max_f32 %0, %1, %2" : "=v"(t[nt][p][r]) : "v"(v), "v"(m));
             }
 }
 

@@ -404,7 +404,7 @@ __device__ __forceinline__ void gemm16_single(f4 (&acc)[2][P], const WPre &w, BL
 #define BALF_STAMPS 0
 #endif
 #if BALF_STAMPS
-__device__ unsigned long long g_stamp_sum[16][24];
+__device__ unsigned long long g_stamp_sum[16][40];
 __device__ unsigned long long g_stamp_cnt[16];
 #define STAMP_DECL unsigned long long st_prev = 0; (void)st_prev
 #define STAMP(i)                                                                                        \
@@ -419,9 +419,40 @@ __device__ unsigned long long g_stamp_cnt[16];
         }                                                                                               \
         st_prev = st_now;                                                                               \
     } while (0)
+// The same for straight-line kernels, without memory traffic between the stamps (an atomic in flight would be waited
+// for by the next vmcnt wait of the code under test): lane i of wave 0 keeps the cycles of phase i in a register, one
+// batch of atomics at the end.
+#define STAMPV_DECL unsigned long long sv_prev = 0; unsigned sv_vec = 0; (void)sv_prev
+#define STAMPV(i)                                                                                       \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        unsigned long long sv_now;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv_now)::"memory");                  \
+        {                                                                                               \
+            const unsigned sv_d = __builtin_amdgcn_readfirstlane((unsigned)(sv_now - sv_prev));         \
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(sv_vec) : "s"(sv_d), "n"(i));              \
+        }                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        sv_prev = sv_now;                                                                               \
+    } while (0)
+#define STAMPV_FLUSH()                                                                                  \
+    do {                                                                                                \
+        if ((threadIdx.x & 63) == 0) {      /* where the waves of a workgroup land: SIMD id per wave slot */ \
+            unsigned hw;                                                                                \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                            \
+            atomicAdd(&g_stamp_sum[8 + STAMP_KID][((threadIdx.x >> 6) & 7) * 4 + ((hw >> 4) & 3)], 1ull); \
+        }                                                                                               \
+        if (threadIdx.x < 40) {                                                                         \
+            if (threadIdx.x > 0) atomicAdd(&g_stamp_sum[STAMP_KID][threadIdx.x], (unsigned long long)sv_vec); \
+            else atomicAdd(&g_stamp_cnt[STAMP_KID], 1ull);                                              \
+        }                                                                                               \
+    } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
+#define STAMPV_DECL
+#define STAMPV(i)
+#define STAMPV_FLUSH()
 #endif
 // add the value of lane (l + n) mod 16 of the same 16-lane row (DPP row_ror): 4 steps = sum over the row in every lane
 template <int N>
@@ -1679,11 +1710,11 @@ int run_pool16(int s, const float *T, const float *R, const float *scale, int B,
 }  // namespace
 
 #if BALF_STAMPS
-extern "C" int balf_debug_stamps(unsigned long long *sums /*[16*24]*/, unsigned long long *cnt /*[16]*/, int reset) {
+extern "C" int balf_debug_stamps(unsigned long long *sums /*[16*40]*/, unsigned long long *cnt /*[16]*/, int reset) {
     if (hipMemcpyFromSymbol(sums, HIP_SYMBOL(g_stamp_sum), sizeof(g_stamp_sum)) != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_stamp_cnt), sizeof(g_stamp_cnt)) != hipSuccess) return -1;
     if (reset) {
-        static unsigned long long z[16 * 24];
+        static unsigned long long z[16 * 40];
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), z, sizeof(g_stamp_sum)) != hipSuccess) return -1;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_cnt), z, sizeof(g_stamp_cnt)) != hipSuccess) return -1;
     }

@@ -37,16 +37,30 @@ struct CsW {
     HL a[2][2];       // [K-step of the pair][row tile]
 };
 
-// weight tile (t, ks) of this wave at wbase + (t * kstot + ks) * 2048 (+ 1024: lo), straight from L2
+// Weight tile (t, ks) of this wave at byte wbase + (t * kstot + ks) * 2048 (+ 1024: lo) of the blob, straight from L2.
+// Buffer loads: the blob's resource descriptor and every tile offset are wave-uniform (scalar registers), the lane's
+// 16 bytes are one shared 32-bit vector offset -- no vector instructions for addresses (global_load with 64-bit lane
+// pointers cost ~100 of them per token group).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct CsBlob {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned loff;                                        // lane * 16
+    __device__ __forceinline__ f4 vec(unsigned off) const {
+        return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, loff, off, 0));
+    }
+    __device__ __forceinline__ h8 frag(unsigned off) const {
+        return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, loff, off, 0));
+    }
+};
 template <int NSTEP = 2>
-__device__ __forceinline__ void cs_wload(CsW &w, const char *wbase, int kstot, int ks) {
+__device__ __forceinline__ void cs_wload(CsW &w, const CsBlob &bl, unsigned wbase, int kstot, int ks) {
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const char *p = wbase + ((size_t)t * kstot + ks + s) * 2048;
-            w.a[s][t].hi = *reinterpret_cast<const h8 *>(p);
-            w.a[s][t].lo = *reinterpret_cast<const h8 *>(p + 1024);
+            const unsigned o = wbase + (unsigned)((t * kstot + ks + s) * 2048);
+            w.a[s][t].hi = bl.frag(o);
+            w.a[s][t].lo = bl.frag(o + 1024);
         }
 }
 
@@ -55,7 +69,7 @@ __device__ __forceinline__ void cs_wload(CsW &w, const char *wbase, int kstot, i
 // Linear is otherwise exposed: the workgroup's waves move in step, nothing else covers it); inside the loop the next
 // pair is requested while the current one is consumed.  bsrc(ks) -> the shared B fragments of K-step ks, [p][hi|lo][lane].
 template <int KSN, typename BS>
-__device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, const char *wbase, int kstot, BS bsrc, int lane) {
+__device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, const CsBlob &bl, unsigned wbase, int kstot, BS bsrc, int lane) {
     static_assert(KSN == 1 || KSN % 2 == 0, "K-steps come in pairs (or a single one: conv0 of stage 2)");
     auto compute = [&](const CsW &w, int ks) {
 #pragma unroll
@@ -88,11 +102,11 @@ __device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, con
         CsW a0 = first, a1;
 #pragma unroll
         for (int ks = 0; ks < KSN; ks += 4) {
-            cs_wload(a1, wbase, kstot, ks + 2);
+            cs_wload(a1, bl, wbase, kstot, ks + 2);
             if (BALF_CS_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);     // the requests go out before the MFMAs they hide behind
             compute(a0, ks);
             if (BALF_CS_SCHED >= 2) __builtin_amdgcn_sched_barrier(0);
-            if (ks + 4 < KSN) cs_wload(a0, wbase, kstot, ks + 4);
+            if (ks + 4 < KSN) cs_wload(a0, bl, wbase, kstot, ks + 4);
             if (BALF_CS_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);
             compute(a1, ks + 2);
             if (BALF_CS_SCHED >= 2) __builtin_amdgcn_sched_barrier(0);
@@ -117,6 +131,8 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
     const StageOff &S = A.off;
     const BranchOff &Br = S.br[MODE];
     const char *bb = reinterpret_cast<const char *>(blob);
+    const CsBlob bl{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(blob), 0, 0x7fffffff, 0x27000), (unsigned)lane * 16u};
+    const CsBlob bq{bl.rsrc, (unsigned)q * 16u};                                           // per-channel vectors: channels 4 q .. 4 q + 3
     const int c0 = 32 * wave;                                                              // this wave's first channel
 
     const int H = A.H, W = A.W, fh = H / 8, fw = W / 8;
@@ -166,8 +182,8 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
     struct Bias { f4 b[2]; };
     auto bias_load = [&](int off_floats) {                    // this wave's 32 channels of a bias vector (requested early)
         Bias r;
-        r.b[0] = ldg4(blob + off_floats + c0 + 4 * q);
-        r.b[1] = ldg4(blob + off_floats + c0 + 16 + 4 * q);
+        r.b[0] = bq.vec((unsigned)(off_floats + c0) * 4u);
+        r.b[1] = bq.vec((unsigned)(off_floats + c0 + 16) * 4u);
         return r;
     };
     auto bias_fill = [&](f4 (&t)[2][4], const Bias &b) {
@@ -177,32 +193,49 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
             for (int p = 0; p < P; ++p) t[nt][p] = b.b[nt];
     };
     auto wptr = [&](int w_off_floats, int row_tile0, int kstot, int ks0) {      // first weight tile of this wave
-        return bb + (size_t)w_off_floats * 4 + ((size_t)(row_tile0 + 2 * wave) * kstot + ks0) * 2048 + lane * 16;
+        return (unsigned)w_off_floats * 4u + (unsigned)(((row_tile0 + 2 * wave) * kstot + ks0) * 2048);
     };
     auto from_bx = [&](int ks) { return bx + ks * (4 * 2 * 64); };
     // per-pixel LayerNorm statistics over ALL channels: this wave's partial sums through LDS (one barrier)
     auto ln_stats_all = [&](const f4 (&x)[2][4], float (&rstd)[P], float (&shift)[P]) {
+        // this wave's partial (sum, sumsq) per pixel: 8 values per lane, reduced over the four lane quarters as a
+        // reduce-scatter (6 row swaps + 6 adds instead of an all-reduce per pixel tile) -- quarter 0 ends up with
+        // (S_0, S_2), quarter 1 with (SS_0, SS_2), quarter 2 with (S_1, S_3), quarter 3 with (SS_1, SS_3) of its
+        // pixel column, and every lane writes its pair: stats[wave][quarter][li]
+        {
+            auto u = [](float v) { return __builtin_bit_cast(unsigned, v); };
+            auto f = [](unsigned v) { return __builtin_bit_cast(float, v); };
+            float c[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            float s = 0.0f, ss = 0.0f;
+            for (int p = 0; p < P; ++p) {
+                float s = 0.0f, ss = 0.0f;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s += x[nt][p][r]; ss = fmaf(x[nt][p][r], x[nt][p][r], ss); }
-            quarter_allreduce2(s, ss);
-            if (q == 0) *reinterpret_cast<float2 *>(stats + ((wave * 4 + p) * 16 + li) * 2) = make_float2(s, ss);
+                    for (int r = 0; r < 4; ++r) { s += x[nt][p][r]; ss = fmaf(x[nt][p][r], x[nt][p][r], ss); }
+                const auto r0 = __builtin_amdgcn_permlane16_swap(u(s), u(ss), false, false);   // rows [s0 ss0 s2 ss2], [s1 ss1 s3 ss3]
+                c[p] = f(r0[0]) + f(r0[1]);                                                    // [S01 SS01 S23 SS23]
+            }
+            const auto r01 = __builtin_amdgcn_permlane32_swap(u(c[0]), u(c[1]), false, false);  // [c0.lo32 c1.lo32], [c0.hi32 c1.hi32]
+            const auto r23 = __builtin_amdgcn_permlane32_swap(u(c[2]), u(c[3]), false, false);
+            *reinterpret_cast<float2 *>(stats + (wave * 64 + lane) * 2) =
+                make_float2(f(r01[0]) + f(r01[1]), f(r23[0]) + f(r23[1]));
         }
         barrier();
+        float S[P] = {0.0f, 0.0f, 0.0f, 0.0f}, SS[P] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float2 a = *reinterpret_cast<const float2 *>(stats + (w * 64 + 0 * 16 + li) * 2);
+            const float2 b = *reinterpret_cast<const float2 *>(stats + (w * 64 + 1 * 16 + li) * 2);
+            const float2 cc = *reinterpret_cast<const float2 *>(stats + (w * 64 + 2 * 16 + li) * 2);
+            const float2 d = *reinterpret_cast<const float2 *>(stats + (w * 64 + 3 * 16 + li) * 2);
+            S[0] += a.x; S[2] += a.y; SS[0] += b.x; SS[2] += b.y;
+            S[1] += cc.x; S[3] += cc.y; SS[1] += d.x; SS[3] += d.y;
+        }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            float s = 0.0f, ss = 0.0f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const float2 v = *reinterpret_cast<const float2 *>(stats + ((w * 4 + p) * 16 + li) * 2);
-                s += v.x; ss += v.y;
-            }
-            const float mean = s * (1.0f / C);
-            const float var = fmaf(ss, 1.0f / C, -mean * mean);
+            const float mean = S[p] * (1.0f / C);
+            const float var = fmaf(SS[p], 1.0f / C, -mean * mean);
             rstd[p] = __builtin_amdgcn_rsqf(max0(var) + kLnEps);
             shift[p] = -mean * rstd[p];
         }
@@ -232,47 +265,47 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
 
     // Every Linear's first weight fragments and bias are requested before the epilogue / barriers in front of it.
     // ---- x0 = relu(conv0(X)) ----
-    const char *w_c0 = wptr(S.conv0_w, 0, KI, 0), *w_q1 = wptr(S.q1_w, MODE * NT, KS, 0);
-    const char *w_d1a = wptr(Br.d1_w, 0, KS, 0), *w_d1b = wptr(Br.d1_w, NT, KS, 0), *w_d2 = wptr(Br.d2_w, 0, KS, 0);
+    const unsigned w_c0 = wptr(S.conv0_w, 0, KI, 0), w_q1 = wptr(S.q1_w, MODE * NT, KS, 0);
+    const unsigned w_d1a = wptr(Br.d1_w, 0, KS, 0), w_d1b = wptr(Br.d1_w, NT, KS, 0), w_d2 = wptr(Br.d2_w, 0, KS, 0);
     f4 x0[2][4];
     {
         CsW w;
-        cs_wload<(KI == 1 ? 1 : 2)>(w, w_c0, KI, 0);
+        cs_wload<(KI == 1 ? 1 : 2)>(w, bl, w_c0, KI, 0);
         bias_fill(x0, bias_load(S.conv0_b));
-        cs_linear<KI>(x0, w, w_c0, KI, from_bx, lane);
+        cs_linear<KI>(x0, w, bl, w_c0, KI, from_bx, lane);
     }
     CsW wn;                                                    // the NEXT Linear's first fragments
-    cs_wload(wn, w_q1, KS, 0);
+    cs_wload(wn, bl, w_q1, KS, 0);
     Bias bn = bias_load(S.q1_b + MODE * C);
     relu(x0);
     ln_publish(x0);
     // ---- z = GELU(dense1 half) ----
     f4 z[2][4];
     bias_fill(z, bn);
-    cs_linear<KS>(z, wn, w_q1, KS, from_bx, lane);
-    cs_wload(wn, w_d1a, KS, 0);
+    cs_linear<KS>(z, wn, bl, w_q1, KS, from_bx, lane);
+    cs_wload(wn, bl, w_d1a, KS, 0);
     bn = bias_load(Br.d1_b);
     gelu<false>(z);
     ln_publish(z);
     // ---- branch dense1: a half, b half (same B operand) ----
     f4 ga[2][4];
     bias_fill(ga, bn);
-    cs_linear<KS>(ga, wn, w_d1a, KS, from_bx, lane);
-    cs_wload(wn, w_d1b, KS, 0);
+    cs_linear<KS>(ga, wn, bl, w_d1a, KS, from_bx, lane);
+    cs_wload(wn, bl, w_d1b, KS, 0);
     bn = bias_load(Br.d1_b + C);
     gelu<false>(ga);
     {
         f4 gb[2][4];
         bias_fill(gb, bn);
-        cs_linear<KS>(gb, wn, w_d1b, KS, from_bx, lane);
-        cs_wload(wn, w_d2, KS, 0);                             // dense2's first fragments travel through the token mix
+        cs_linear<KS>(gb, wn, bl, w_d1b, KS, from_bx, lane);
+        cs_wload(wn, bl, w_d2, KS, 0);                             // dense2's first fragments travel through the token mix
         bn = bias_load(Br.d2_b);
         gelu<false>(gb);
         float rstd[P], shift[P];
         ln_stats_all(gb, rstd, shift);                         // gating LayerNorm (affine) over all C channels
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const f4 gg = ldg4(blob + Br.gln_g + c0 + 16 * nt + 4 * q), be = ldg4(blob + Br.gln_b + c0 + 16 * nt + 4 * q);
+            const f4 gg = bq.vec((unsigned)(Br.gln_g + c0 + 16 * nt) * 4u), be = bq.vec((unsigned)(Br.gln_b + c0 + 16 * nt) * 4u);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v[P];
@@ -298,7 +331,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
                 a[ct][kk].hi = *reinterpret_cast<const h8 *>(row);
                 a[ct][kk].lo = *reinterpret_cast<const h8 *>(row + kS1C * kS1Pitch);
             }
-        const f4 mbv = ldg4(blob + Br.mix_b + 4 * li);
+        const f4 mbv = CsBlob{bl.rsrc, (unsigned)li * 16u}.vec((unsigned)Br.mix_b * 4u);
 #pragma unroll
         for (int pt = 0; pt < P; ++pt) {
             HL w0, w1;
@@ -331,7 +364,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
     // ---- branch dense2 + residual ----
     f4 o[2][4];
     bias_fill(o, bn);
-    cs_linear<KS>(o, wn, w_d2, KS, from_bx, lane);
+    cs_linear<KS>(o, wn, bl, w_d2, KS, from_bx, lane);
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -339,7 +372,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
             store_frag_px(A.U, pix0 + p * pstep, C, wave, q, split8(o0, o1));
         }
     } else {
-        const char *w_q2 = wptr(S.q2_w, 0, 2 * KS, 0), *w_r1 = wptr(S.r1_w, 0, KS, 0), *w_r2 = wptr(S.r2_w, 0, KS, 0);
+        const unsigned w_q2 = wptr(S.q2_w, 0, 2 * KS, 0), w_r1 = wptr(S.r1_w, 0, KS, 0), w_r2 = wptr(S.r2_w, 0, KS, 0);
         // this wave's four u' fragments (of KS x 4): written by the grid kernel just before, served from L2 / the
         // Infinity Cache; requested here (not before dense2: 32 more live registers there mean spills)
         static_assert(KS * 4 == 4 * NW, "four u' fragments per wave");
@@ -349,7 +382,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
             const int fi = 4 * wave + f, kk = fi >> 2, p = fi & 3;
             ub[f] = load_frag_px(A.U, pix0 + p * pstep, C, kk, q);
         }
-        cs_wload(wn, w_q2, 2 * KS, 0);
+        cs_wload(wn, bl, w_q2, 2 * KS, 0);
         bn = bias_load(S.q2_b);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -367,9 +400,9 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
         // RSHMAG.dense2 over cat[u', v']: K-steps 0 .. KS-1 from the u' fragments, KS .. 2KS-1 from v'
         f4 x1[2][4];
         bias_fill(x1, bn);
-        cs_linear<2 * KS>(x1, wn, w_q2, 2 * KS,
+        cs_linear<2 * KS>(x1, wn, bl, w_q2, 2 * KS,
                           [&](int ks) { return ks < KS ? bu + ks * (4 * 2 * 64) : bx + (ks - KS) * (4 * 2 * 64); }, lane);
-        cs_wload(wn, w_r1, KS, 0);
+        cs_wload(wn, bl, w_r1, KS, 0);
         bn = bias_load(S.r1_b);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -381,8 +414,8 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
         ln_publish(x1);
         f4 m1[2][4];
         bias_fill(m1, bn);
-        cs_linear<KS>(m1, wn, w_r1, KS, from_bx, lane);
-        cs_wload(wn, w_r2, KS, 0);
+        cs_linear<KS>(m1, wn, bl, w_r1, KS, from_bx, lane);
+        cs_wload(wn, bl, w_r2, KS, 0);
         bn = bias_load(S.r2_b);
         lrelu(m1);
         barrier();                                             // everyone is done with conv1's B operand
@@ -390,7 +423,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, 2) void stage_cs_kernel16(Stage
         barrier();
         f4 t[2][4];
         bias_fill(t, bn);
-        cs_linear<KS>(t, wn, w_r2, KS, from_bx, lane);
+        cs_linear<KS>(t, wn, bl, w_r2, KS, from_bx, lane);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             f4 s = t[nt][0];

@@ -1,0 +1,38 @@
+"""Per-phase cycle breakdown of the channel-split stage kernels (diagnostic build libbalf_hip_stamps.so: -DBALF_STAMPS=1
+-DBALF_S1_WAVE=0): wave 0 of every workgroup stamps s_memtime before and after every Linear and every barrier of its
+token group (the ids are the STAMP(i) points of stage_cs_f16.h, in program order)."""
+import ctypes as C, os, sys
+import torch
+sys.path.insert(0, ".")
+os.environ["BALF_HIP_LIB"] = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else "balf_amd/libbalf_hip_stamps.so")
+from balf_amd import arch
+from balf_amd.model import get_model
+from balf_amd.utils import synth
+m = get_model.load_model(arch.DEFAULT_MODEL_CFG); m.load_state_dict(synth.synthetic_state_dict(1)); m.precision = "fp16"
+m = m.eval().cuda()
+x = torch.rand((8, 3, 1088, 1920), device="cuda")
+raw = C.CDLL(os.environ["BALF_HIP_LIB"])
+NS = 40
+sums = (C.c_ulonglong * (16 * NS))(); cnt = (C.c_ulonglong * 16)()
+m(x, want_logits=False); torch.cuda.synchronize()
+raw.balf_debug_stamps(sums, cnt, 1)
+for _ in range(2): m(x, want_logits=False)
+torch.cuda.synchronize()
+raw.balf_debug_stamps(sums, cnt, 0)
+common = ["", "in", "BAR", "pre", "conv0", "epi x0", "BAR", "pre", "q1", "epi z", "BAR", "pre", "d1b", "epi gb", "BAR", "tile+pre",
+          "d1a", "epi ga+mix+pub", "BAR", "pre", "d2"]
+grid = common + ["res+U"]
+block = common + ["u' req+res", "BAR", "pub v'+u'", "BAR", "pre", "q2", "res+R+pub x1", "BAR", "pre", "r1", "epi m1+pub", "BAR", "pre", "r2", "T+sums"]
+for kid in range(2, 8):
+    n = cnt[kid]
+    if not n: continue
+    names = block if kid % 2 else grid
+    v = [sums[kid * NS + i] / n for i in range(NS)]
+    tot = sum(v[1:])
+    bar = sum(v[i] for i in range(1, len(names)) if names[i] == "BAR")
+    gemm = sum(v[i] for i in range(1, len(names)) if names[i] in ("conv0", "q1", "d1a", "d1b", "d2", "q2", "r1", "r2"))
+    print(f"C={[32,64,128,256][kid//2]} {'block' if kid%2 else 'grid'}: {n} groups, {tot:8.0f} cycles/group (barrier waits {bar:.0f}, Linears {gemm:.0f}):  " +
+          "  ".join(f"{names[i]}={v[i]:.0f}" for i in range(1, len(names))))
+for kid in range(2, 8):
+    if cnt[kid]:
+        print(f"kid {kid}: SIMD of wave slot w (rows) : " + " | ".join(" ".join(str(sums[(8 + kid) * NS + w * 4 + sd]) for sd in range(4)) for w in range(8)))
