@@ -277,7 +277,9 @@ struct StageArgs {
     float *U;             // [B,H,W,C] grid-branch output u'
     float *T;             // [B,H,W,C] RCAB body output t
     float *R;             // [B,H,W,C] x1 + x0
-    float *partial;       // [B, wgs_per_image, C] channel sums of t
+    float *partial;       // [B, wgs_per_image, C] channel sums of t (stage 1, fused tail: of the RCAB's hidden layer)
+    const float *scale;   // stage-1 tail kernel only: [B, C] squeeze-excite scale
+    float *out;           // stage-1 tail kernel only: next stage's input, fragment format [B, H/2, W/2, C]
 };
 
 struct InputU8 {           // optional raw-image input of the forward (ch = 0: none)
@@ -337,18 +339,29 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const float *__restrict_
     }
 }
 
+// hidden_sums != 0: the chunk sums are those of the RCAB's hidden layer h = lrelu(conv1(.)) (stage 1 with the fused tail
+// kernel, stage1_f16.h); conv2 is linear, so mean(t) = conv2_w mean(h) + conv2_b.
 template <int C>
 __global__ __launch_bounds__(256) void se_kernel(const float *blob, StageOff S, const float *chunk, float inv_hw,
-                                                 float *scale) {
+                                                 float *scale, int hidden_sums) {
     __shared__ float s_mean[C];
+    __shared__ float s_in[C];
     __shared__ float s_hid[C / 4];
     const int n = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = 0.0f;
         for (int k = 0; k < kSeChunks; ++k) acc += chunk[((long)n * kSeChunks + k) * C + c];
-        s_mean[c] = acc * inv_hw;
+        (hidden_sums ? s_in : s_mean)[c] = acc * inv_hw;
     }
     __syncthreads();
+    if (hidden_sums) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float acc = blob[S.r2_b + c];
+            for (int k = 0; k < C; ++k) acc += blob[S.r2_plain + c * C + k] * s_in[k];
+            s_mean[c] = acc;
+        }
+        __syncthreads();
+    }
     for (int h = threadIdx.x; h < C / 4; h += 256) {
         float acc = blob[S.se0_b + h];
         for (int c = 0; c < C; ++c) acc += blob[S.se0_w + h * C + c] * s_mean[c];

@@ -404,7 +404,7 @@ int run_stage(const float *blob, int s, const float *X, const InputU8 &u8, int B
     BALF_PROF(4 * s + 2, st, {
         hipLaunchKernelGGL(se_reduce_kernel<C>, dim3(B * kSeChunks), dim3(256), 0, st, partial, per_img, chunk);
         hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], chunk,
-                           1.0f / ((float)H * (float)W), scale);
+                           1.0f / ((float)H * (float)W), scale, 0);
     });
     BALF_LAUNCH_CHECK();
     return BALF_OK;

@@ -1689,7 +1689,7 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
     BALF_PROF(4 * s + 2, st, {
         hipLaunchKernelGGL(se_reduce_kernel<C>, dim3(B * kSeChunks), dim3(256), 0, st, partial, per_img, chunk);
         hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], chunk,
-                           1.0f / ((float)H * (float)W), scale);
+                           1.0f / ((float)H * (float)W), scale, (C == 32 && BALF_S1_WAVE != 0 && BALF_S1_FUSE != 0) ? 1 : 0);
     });
     BALF_LAUNCH_CHECK();
     return BALF_OK;
@@ -1703,6 +1703,24 @@ int run_pool16(int s, const float *T, const float *R, const float *scale, int B,
     if (blocks > 256 * 16) blocks = 256 * 16;
     BALF_PROF(4 * s + 3, st,
               hipLaunchKernelGGL(pool_kernel16<C>, dim3((unsigned)blocks), dim3(256), 0, st, T, R, scale, B, H, W, out));
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}
+
+// Stage-1 tail (stage1_kernel16<2>): x1 (in R), the image and the SE scale -> the next stage's input.
+int run_tail16(const float *blob, const float *X, const InputU8 &u8, const float *R, const float *scale, int B, int H, int W,
+               float *out, hipStream_t st) {
+    StageArgs a{blob, kLayout.st[0], X, u8.p, u8.ch, u8.h, u8.w, u8.top, u8.left, B, H, W, nullptr, nullptr,
+                const_cast<float *>(R), nullptr, scale, out};
+    auto k = u8.ch ? stage1_kernel16<2, true> : stage1_kernel16<2, false>;
+    constexpr int lds = s1_lds_bytes<2>();
+    static_assert(lds <= 160 * 1024, "stage-1 tail LDS image");
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return BALF_ERR_LAUNCH;
+    const long groups = (long)B * (H / 8) * (W / 8);
+    long b = (groups + s1_waves<2>() - 1) / s1_waves<2>();
+    b = (b + 7) / 8 * 8;
+    BALF_PROF(3, st, hipLaunchKernelGGL(k, dim3((unsigned)(b < 256 ? b : 256)), dim3(s1_waves<2>() * 64), lds, st, a));
     BALF_LAUNCH_CHECK();
     return BALF_OK;
 }
@@ -1738,7 +1756,9 @@ int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
         if (u8.ch) u8b.p = u8.p + (size_t)b0 * u8.h * u8.w * u8.ch;
         int rc;
         if ((rc = run_stage16<32, 3>(blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_pool16<32>(0, T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
+        if (BALF_S1_WAVE != 0 && BALF_S1_FUSE != 0) {
+            if ((rc = run_tail16(blob, x, u8b, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
+        } else if ((rc = run_pool16<32>(0, T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
         if ((rc = run_stage16<64, 32>(blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool16<64>(1, T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
         if ((rc = run_stage16<128, 64>(blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;

@@ -39,6 +39,7 @@ struct StageOff {
     int se0_w, se0_b;             // calayer.excite.0 [C/4, C] plain
     int se2_w, se2_b;             // calayer.excite.2 [C, C/4] plain
     int conv2_w, conv2_b;         // .conv2 [C, C] frags (stage 4 only; dead weight elsewhere)
+    int r2_plain;                 // RCAB .conv2 again, plain row-major fp32 [C, C]: mean(conv2(h)) = conv2(mean(h)) in the SE kernel
 };
 
 struct Layout {
@@ -77,6 +78,7 @@ constexpr Layout make_layout() {
         S.se0_w = take(C / 4 * C); S.se0_b = take(C / 4);
         S.se2_w = take(C * (C / 4)); S.se2_b = take(C);
         S.conv2_w = take(C * C); S.conv2_b = take(C);
+        S.r2_plain = take(C * C);
     }
     L.head_w = take(kHeadNPad * kC[3]);
     L.head_b = take(kHeadNPad);

@@ -33,7 +33,7 @@ constexpr int kS1D2 = kS1Mix + 8 * 2048;                       // 2 row tiles
 constexpr int kS1Q2 = kS1D2 + 2 * 2048;                        // block only: 2 row tiles x 2 K-steps
 constexpr int kS1R1 = kS1Q2 + 4 * 2048;
 constexpr int kS1R2 = kS1R1 + 2 * 2048;
-template <int MODE> constexpr int s1_weight_bytes() { return MODE == 0 ? kS1Q2 : kS1R2 + 2 * 2048; }
+template <int MODE> constexpr int s1_weight_bytes() { return MODE == 0 ? kS1Q2 : kS1R2 + 2 * 2048; }   // MODE 2 (tail): the block image
 // ... then per-channel parameters (floats) ...
 enum S1Par { kS1pConv0B = 0, kS1pQ1B = 32, kS1pD1B = 64, kS1pGlnG = 128, kS1pGlnB = 160, kS1pMixB1 = 192, kS1pD2B = 256,
              kS1pQ2B = 288, kS1pR1B = 320, kS1pR2B = 352, kS1pLut = 384, kS1ParFloats = 640 };
@@ -44,9 +44,12 @@ enum S1Par { kS1pConv0B = 0, kS1pQ1B = 32, kS1pD1B = 64, kS1pGlnG = 128, kS1pGln
 #ifndef BALF_S1_NW1
 #define BALF_S1_NW1 8
 #endif
-template <int MODE> constexpr int s1_waves() { return MODE == 0 ? BALF_S1_NW0 : BALF_S1_NW1; }   // 3 / 2 waves per SIMD
+#ifndef BALF_S1_NW2
+#define BALF_S1_NW2 12
+#endif
+template <int MODE> constexpr int s1_waves() { return MODE == 0 ? BALF_S1_NW0 : MODE == 1 ? BALF_S1_NW1 : BALF_S1_NW2; }   // 3 / 2 / 3 waves per SIMD
 template <int MODE> constexpr int s1_lds_bytes() {
-    return s1_weight_bytes<MODE>() + kS1ParFloats * 4 + s1_waves<MODE>() * kS1BtBytes;
+    return s1_weight_bytes<MODE>() + kS1ParFloats * 4 + (MODE == 2 ? 0 : s1_waves<MODE>() * kS1BtBytes);   // (no token mix in the tail)
 }
 
 // sum over the four lanes l, l^16, l^32, l^48 of TWO values at once with the gfx950 row swaps (pure VALU; the
@@ -164,6 +167,9 @@ __device__ __forceinline__ const T *uniform_ptr(const T *p) {
     return reinterpret_cast<const T *>(((unsigned long long)hi << 32) | lo);
 }
 
+#ifndef BALF_S1_FUSE
+#define BALF_S1_FUSE 1       // 1: the block kernel stores x1 and the channel sums of the RCAB's hidden layer only; tail kernel (MODE 2)
+#endif
 #ifndef BALF_S1_STRICT
 #define BALF_S1_STRICT 0     // 1: every hand-placed wait drains the queue (debugging aid)
 #endif
@@ -177,7 +183,9 @@ __device__ __forceinline__ const T *uniform_ptr(const T *p) {
 template <int MODE, bool U8>
 __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(StageArgs A) {
     constexpr int C = kS1C, P = 4, NW = s1_waves<MODE>(), NTHR = NW * 64;
-    constexpr int STAMP_KID = MODE; (void)STAMP_KID;
+    constexpr int BM = MODE == 0 ? 0 : 1;                        // branch whose weights / token geometry this kernel uses
+    constexpr bool TAIL = MODE == 2;                             // the stage's tail (see the loop body)
+    constexpr int STAMP_KID = BM; (void)STAMP_KID;
     STAMP_DECL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *par = reinterpret_cast<float *>(smem_raw + s1_weight_bytes<MODE>());
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float *blob = A.blob;
     const StageOff &S = A.off;
-    const BranchOff &Br = S.br[MODE];
+    const BranchOff &Br = S.br[BM];
 
     // ---- stage the weights, parameters and the uint8 table once per workgroup ----
     {
@@ -194,10 +202,10 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             for (int i = threadIdx.x * 16; i < bytes; i += NTHR * 16)
                 *reinterpret_cast<uint4 *>(smem_raw + dst + i) = *reinterpret_cast<const uint4 *>(s + i);
         };
-        copy(kS1Q1, S.q1_w + MODE * (2 * 512), 2 * 2048);      // rows MODE*C .. : tiles 2*MODE, 2*MODE+1 (512 floats each)
+        copy(kS1Q1, S.q1_w + BM * (2 * 512), 2 * 2048);        // rows BM*C .. : tiles 2*BM, 2*BM+1 (512 floats each)
         copy(kS1D1, Br.d1_w, 4 * 2048);
         copy(kS1D2, Br.d2_w, 2 * 2048);
-        if (MODE == 1) {
+        if (BM == 1) {
             copy(kS1Q2, S.q2_w, 4 * 2048);                       // tiles (nt, ks): nt*2 + ks
             copy(kS1R1, S.r1_w, 2 * 2048);
             copy(kS1R2, S.r2_w, 2 * 2048);
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         for (int i = threadIdx.x; i < kS1ParFloats; i += NTHR) {
             float v;
             if (i < kS1pQ1B) v = blob[S.conv0_b + i];
-            else if (i < kS1pD1B) v = blob[S.q1_b + MODE * C + (i - kS1pQ1B)];
+            else if (i < kS1pD1B) v = blob[S.q1_b + BM * C + (i - kS1pQ1B)];
             else if (i < kS1pGlnG) v = blob[Br.d1_b + (i - kS1pD1B)];
             else if (i < kS1pGlnB) v = blob[Br.gln_g + (i - kS1pGlnG)];
             else if (i < kS1pMixB1) v = blob[Br.gln_b + (i - kS1pGlnB)];
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         const float *xb = A.X + (long)g.n * 3 * (long)hw;
         const float *x0p = uniform_ptr(xb), *x1p = uniform_ptr(xb + hw), *x2p = uniform_ptr(xb + 2 * hw);
         if (q == 0) {
-            if constexpr (MODE == 1) {
+            if constexpr (BM == 1) {
                 asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %5\n\t"
                              "global_load_dwordx4 %2, %3, %6"
                              : "+v"(rawv[0]), "+v"(rawv[1]), "+v"(rawv[2]) : "v"(voff), "s"(x0p), "s"(x1p), "s"(x2p) : "memory");
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     Pos nxt = decompose(item);
     unsigned raw[P][3] = {};
     f4 rawv[3] = {};
-    if (!U8 && item < total) {
+    if (!U8 && !TAIL && item < total) {
         issue_raw(geo(nxt), raw, rawv);
         // the first group has no older stores in front of its pixels: drain (the counted wait in the loop assumes them)
         if constexpr (MODE == 1)
@@ -352,10 +360,29 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         if (item + stride < total) nxt = advance(nxt);           // (the last group re-requests its own pixels)
         const long pix0 = g.pix0;
         if (U8) load_raw_u8(g, raw);
+        // (tail) plain loads, no prefetch across groups: three waves per SIMD cover the latency, and with two stores per
+        // group there is no store queue to count around.  x1 as the block kernel left it, this image's SE scale.
+        f4 x1t[TAIL ? 2 : 1][TAIL ? P : 1], sct[2];
+        if constexpr (TAIL) {
+            if constexpr (!U8) {
+                if (q == 0) {
+                    const float *xb = A.X + (long)g.n * 3 * (long)hw + (long)g.y * W + g.x0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rawv[k] = *reinterpret_cast<const f4 *>(xb + (long)k * hw);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                sct[nt] = *reinterpret_cast<const f4 *>(A.scale + (long)g.n * C + 16 * nt + 4 * q);
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    x1t[nt][p] = *reinterpret_cast<const f4 *>(A.R + (pix0 + p * pstep) * C + 16 * nt + 4 * q);
+            }
+        }
         STAMP(0);
         HL bx[P];                                                // conv0's B fragments
         {
-            if constexpr (!U8) {
+            if constexpr (!U8 && !TAIL) {
                 // the input pixels of this group have landed; the previous group's stores may still be in flight
                 if constexpr (MODE == 1)
                     asm volatile(BALF_S1_WAIT_IN : "+v"(rawv[0]), "+v"(rawv[1]), "+v"(rawv[2]) :: "memory");
@@ -371,7 +398,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     if (U8) in[p][k] = (q == 0 && raw[p][k] < 256u) ? par[kS1pLut + (raw[p][k] & 255u)] : 0.0f;
-                    else if (MODE == 1) in[p][k] = rawv[k][p];
+                    else if (BM == 1) in[p][k] = rawv[k][p];
                     else in[p][k] = __builtin_bit_cast(float, raw[p][k]);
                 }
 #pragma unroll
@@ -398,7 +425,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
 #undef BALF_S1_UB
             }
         }
-        if constexpr (!U8) issue_raw(geo(nxt), raw, rawv);       // next group's pixels (12 or 3 loads, always)
+        if constexpr (!U8 && !TAIL) issue_raw(geo(nxt), raw, rawv);   // next group's pixels (12 or 3 loads, always)
         STAMP(1);   // input -> conv0 B fragments (waits for the prefetched pixels), next group's loads issued
         auto conv0 = [&](f4 (&x0v)[2][P]) {                      // x0 = relu(conv0(X)); bit-identical every time
             s1_bias(x0v, par + kS1pConv0B, q);
@@ -407,6 +434,50 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         };
 
         HL b[P];                                                 // B fragments of the next Linear
+        if constexpr (TAIL) {
+            // ---- the stage's tail: x2 = maxpool2x2(x1 + x0 + s * conv2(lrelu(conv1(LN(x1))))) in fragment format ----
+            // The block kernel stored x1 and the channel sums of the RCAB's hidden layer (conv2 is linear: the SE
+            // kernel gets mean(t) from mean(hidden)); the branch itself is recomputed here from x1 -- the same
+            // instructions on the same values as the block kernel's, so t is the t it would have stored -- instead of
+            // a T and an R tensor travelling through HBM (4.3 GB per 8 images at 1088x1920 written and read again).
+            s1_ln_split(x1t, b);
+            f4 m1[2][P];
+            s1_bias(m1, par + kS1pR1B, q);
+            s1_linear(m1, wl + kS1R1, 2048, b);
+            lrelu(m1);
+            s1_split(m1, b);
+            f4 t[2][P];
+            s1_bias(t, par + kS1pR2B, q);
+            s1_linear(t, wl + kS1R2, 2048, b);
+            f4 x0v[2][P];
+            conv0(x0v);
+            // v = r + s t with r = x1 + x0 (the order of operations of pool_kernel16), max over the 2x2 window: the
+            // lane's tokens 2 pp, 2 pp + 1 are horizontal neighbours, the rows 2 j, 2 j + 1 sit in lanes li, li ^ 2
+            f4 mx[2][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v0 = fmaf(t[nt][2 * pp][r], sct[nt][r], x1t[nt][2 * pp][r] + x0v[nt][2 * pp][r]);
+                        const float v1 = fmaf(t[nt][2 * pp + 1][r], sct[nt][r], x1t[nt][2 * pp + 1][r] + x0v[nt][2 * pp + 1][r]);
+                        const float m = __builtin_fmaxf(v0, v1);
+                        const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, m), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
+                        mx[nt][pp][r] = __builtin_fmaxf(m, o);
+                    }
+            // both lanes of a row pair hold the same two pooled pixels: lane li stores pooled column 2 (li & 1) + ((li >> 1) & 1)
+            const int sel = (li >> 1) & 1;
+            f4 o0, o1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o0[r] = sel ? mx[0][1][r] : mx[0][0][r];
+                o1[r] = sel ? mx[1][1][r] : mx[1][0][r];
+            }
+            const long opix = ((long)g.n * (H / 2) + (g.y >> 1)) * (W / 2) + (g.x0 >> 1) + sel;
+            store_frag_px(A.out, opix, C, 0, q, split8(o0, o1));
+        } else {
         {
             f4 x0v[2][P];
             conv0(x0v);
@@ -517,7 +588,10 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
                         x1[nt][p] += x0v[nt][p];
-                        *reinterpret_cast<f4 *>(A.R + (pix0 + p * pstep) * C + 16 * nt + 4 * q) = x1[nt][p] + x0v[nt][p];
+                        if constexpr (BALF_S1_FUSE != 0)         // x1 itself: the tail kernel adds x0 and the scaled RCAB branch
+                            *reinterpret_cast<f4 *>(A.R + (pix0 + p * pstep) * C + 16 * nt + 4 * q) = x1[nt][p];
+                        else
+                            *reinterpret_cast<f4 *>(A.R + (pix0 + p * pstep) * C + 16 * nt + 4 * q) = x1[nt][p] + x0v[nt][p];
                     }
             }
             STAMP(10);  // conv0 again, residuals, R store
@@ -526,18 +600,27 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             s1_bias(m1, par + kS1pR1B, q);
             s1_linear(m1, wl + kS1R1, 2048, b);
             lrelu(m1);
-            s1_split(m1, b);
-            STAMP(11);  // LN + conv1 + lrelu + split
             f4 t[2][P];
-            s1_bias(t, par + kS1pR2B, q);
-            s1_linear(t, wl + kS1R2, 2048, b);
+            if constexpr (BALF_S1_FUSE != 0) {
+                // conv2 is linear: its channel means follow from the means of its input, and the tail kernel
+                // (stage1_tail_kernel16) recomputes the RCAB branch from x1 -- no T tensor through HBM
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) t[nt][p] = m1[nt][p];
+            } else {
+                s1_split(m1, b);
+                STAMP(11);  // LN + conv1 + lrelu + split
+                s1_bias(t, par + kS1pR2B, q);
+                s1_linear(t, wl + kS1R2, 2048, b);
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 f4 s = t[nt][0];
-                *reinterpret_cast<f4 *>(A.T + pix0 * C + 16 * nt + 4 * q) = t[nt][0];
+                if constexpr (BALF_S1_FUSE == 0) *reinterpret_cast<f4 *>(A.T + pix0 * C + 16 * nt + 4 * q) = t[nt][0];
 #pragma unroll
                 for (int p = 1; p < P; ++p) {
-                    *reinterpret_cast<f4 *>(A.T + (pix0 + p * pstep) * C + 16 * nt + 4 * q) = t[nt][p];
+                    if constexpr (BALF_S1_FUSE == 0) *reinterpret_cast<f4 *>(A.T + (pix0 + p * pstep) * C + 16 * nt + 4 * q) = t[nt][p];
                     s += t[nt][p];
                 }
                 // channel sums over the group's 64 pixels (fixed order): over the 16 lanes of the row, then lane li = 0 stores
@@ -547,5 +630,6 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             }
             STAMP(12);  // conv2 + T store + channel sums
         }
+        }   // !TAIL
     }
 }

@@ -197,6 +197,7 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
         copy(blob + S.r1_b, bf.data(), C);
         pack(blob + S.r2_w, t[32], C, C, C);
         copy(blob + S.r2_b, t[33], C);
+        copy(blob + S.r2_plain, t[32], C * C);
         copy(blob + S.se0_w, t[34], (size_t)(C / 4) * C);
         copy(blob + S.se0_b, t[35], C / 4);
         copy(blob + S.se2_w, t[36], (size_t)C * (C / 4));
