@@ -8,8 +8,11 @@ mkdir -p obj
 pids=()
 for f in *.hip; do
   o=obj/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/balf_hip.h -nt "$o" ] || \
-     { [ -f "${f%.hip}.h" ] && [ "${f%.hip}.h" -nt "$o" ]; } || { [ -f layout.h ] && [ layout.h -nt "$o" ]; } || [ prof.h -nt "$o" ] || [ det_common.h -nt "$o" ] || [ split16.h -nt "$o" ]; then
+  stale=0
+  [ -f "$o" ] || stale=1
+  [ "$f" -nt "$o" ] && stale=1
+  for h in *.h ../../include/balf_hip.h; do [ "$h" -nt "$o" ] && stale=1; done   # every TU may include any header here
+  if [ $stale = 1 ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi

@@ -1616,6 +1616,11 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
 #endif
 #include "stage_cs_f16.h"
 
+// stages whose block kernel leaves x1 + hidden-layer sums and whose pool kernel is replaced by a tail kernel
+template <int C> constexpr bool stage_fused() {
+    return C == 32 ? (BALF_S1_WAVE != 0 && BALF_S1_FUSE != 0) : (C >= BALF_CS_MIN_C && C >= 64 && cs_fused<C>());
+}
+
 template <int C, int CIN>
 int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
                 float *partial, float *chunk, float *scale, hipStream_t st) {
@@ -1689,7 +1694,7 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
     BALF_PROF(4 * s + 2, st, {
         hipLaunchKernelGGL(se_reduce_kernel<C>, dim3(B * kSeChunks), dim3(256), 0, st, partial, per_img, chunk);
         hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], chunk,
-                           1.0f / ((float)H * (float)W), scale, (C == 32 && BALF_S1_WAVE != 0 && BALF_S1_FUSE != 0) ? 1 : 0);
+                           1.0f / ((float)H * (float)W), scale, stage_fused<C>() ? 1 : 0);
     });
     BALF_LAUNCH_CHECK();
     return BALF_OK;
@@ -1703,6 +1708,21 @@ int run_pool16(int s, const float *T, const float *R, const float *scale, int B,
     if (blocks > 256 * 16) blocks = 256 * 16;
     BALF_PROF(4 * s + 3, st,
               hipLaunchKernelGGL(pool_kernel16<C>, dim3((unsigned)blocks), dim3(256), 0, st, T, R, scale, B, H, W, out));
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}
+
+// Tail of stages 2-3 (stage_cs_kernel16<C, CIN, 2>): the stage input X, x1 (in R) and the SE scale -> the next stage's input.
+template <int C, int CIN>
+int run_tail_cs16(const float *blob, int s, const float *X, const float *R, const float *scale, int B, int H, int W, float *out,
+                  hipStream_t st) {
+    StageArgs a{blob, kLayout.st[s], X, nullptr, 0, 0, 0, 0, 0, B, H, W, nullptr, nullptr, const_cast<float *>(R), nullptr, scale, out};
+    auto k = stage_cs_kernel16<C, CIN, 2>;
+    constexpr int clds = cs_tail_lds_bytes<C>();
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, clds) != hipSuccess)
+        return BALF_ERR_LAUNCH;
+    const unsigned groups = (unsigned)((long)B * (H / 8) * (W / 8));
+    BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(k, dim3(groups), dim3(cs_waves<C>() * 64), clds, st, a));
     BALF_LAUNCH_CHECK();
     return BALF_OK;
 }
@@ -1756,13 +1776,17 @@ int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
         if (u8.ch) u8b.p = u8.p + (size_t)b0 * u8.h * u8.w * u8.ch;
         int rc;
         if ((rc = run_stage16<32, 3>(blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
-        if (BALF_S1_WAVE != 0 && BALF_S1_FUSE != 0) {
+        if (stage_fused<32>()) {
             if ((rc = run_tail16(blob, x, u8b, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
         } else if ((rc = run_pool16<32>(0, T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
         if ((rc = run_stage16<64, 32>(blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_pool16<64>(1, T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
+        if (stage_fused<64>()) {
+            if ((rc = run_tail_cs16<64, 32>(blob, 1, X2, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
+        } else if ((rc = run_pool16<64>(1, T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
         if ((rc = run_stage16<128, 64>(blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_pool16<128>(2, T, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
+        if (stage_fused<128>()) {
+            if ((rc = run_tail_cs16<128, 64>(blob, 2, X3, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
+        } else if ((rc = run_pool16<128>(2, T, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
         if ((rc = run_stage16<256, 128>(blob, 3, X4, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         HeadArgs ha{blob, kLayout.st[3], kLayout.head_w, kLayout.head_b, kLayout.head_alpha, kLayout.head_beta,
                     T, R, scale, nb, h8, w8,
