@@ -60,21 +60,24 @@ def stage_macs_per_pixel(s: int):
     return grid, block
 
 
-def kernel_bytes_per_launch(name: str, mb: int, hp: int, wp: int, in_bytes_per_px: float = 12.0) -> float:
-    """Algorithmic HBM bytes per launch: what the kernel must read and write once.
-    grid: stage input + u'; block: stage input + u' + t + r; pool: t + r (4 pixels) + pooled output; head: t + r + prob."""
+def kernel_bytes_per_launch(name: str, mb: int, hp: int, wp: int, in_bytes_per_px: float = 12.0,
+                            precision_is_f16: bool = True) -> float:
+    """Algorithmic HBM bytes per launch of the split-f16 schedule: what the kernel must read and write once.
+    grid: stage input + u'; block: stage input + u' + x1 (stages 1-3: the tail kernel recomputes the RCAB branch) or
+    + t + r (stage 4); pool slot = tail kernel: stage input + x1 (4 pixels) + pooled output; head: t + r + prob."""
     if not name.startswith("stage"):
         return 0.0
     s = int(name[5]) - 1
     c, cin = C_STAGE[s], CIN_STAGE[s]
     px = mb * (hp >> s) * (wp >> s)
     x_in = in_bytes_per_px if s == 0 else 4.0 * cin
+    fused = s < 3 and precision_is_f16
     if "grid_branch" in name:
         return (x_in + 4.0 * c) * px
     if "block_branch" in name:
-        return (x_in + 4.0 * c + 8.0 * c) * px
+        return (x_in + 4.0 * c + (4.0 if fused else 8.0) * c) * px
     if "pool" in name:
-        return (8.0 * c + 4.0 * c / 4.0) * px
+        return ((x_in + 4.0 * c if fused else 8.0 * c) + 4.0 * c / 4.0) * px
     if "head" in name:
         return (8.0 * c + 64.0 * 4.0) * px
     return 0.0
@@ -284,7 +287,7 @@ def main():
         name, (ms, n_launch) = max(prof_.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / n_launch
         flops = kernel_flops_per_launch(name, mb, hp, wp)
-        nbytes = kernel_bytes_per_launch(name, mb, hp, wp)
+        nbytes = kernel_bytes_per_launch(name, mb, hp, wp, precision_is_f16=(precision != "fp32"))
         peak_tf = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_FP16_MFMA_TFLOPS
         tf = flops / (avg_ms * 1e-3) / 1e12 if flops else 0.0
         gbs = nbytes / (avg_ms * 1e-3) / 1e9 if nbytes else 0.0
@@ -302,8 +305,9 @@ def main():
             # vector + matrix instructions of one launch priced at what a SIMD charges with >= 2 waves resident (2.6 cycles
             # per VALU instruction, 12.5 per 16x16x32 f16 MFMA beside vector work / 32 per 16x16x4 f32 MFMA;
             # tools/ubench/mfma_valu_mix.hip) over the SIMD cycles of the launch in the same profiled run
-            roof["issue"] = {k_: slot[k_] for k_ in ("valu_insts", "mfma_insts", "issue_share", "wave_wait_share",
-                                                     "wave_issue_stall_share", "waves") if k_ in slot}
+            roof["issue"] = {k_: slot[k_] for k_ in ("valu_insts", "mfma_insts", "issue_share", "valu_busy_share",
+                                                     "mfma_busy_share", "wave_wait_share", "wave_issue_stall_share",
+                                                     "waves") if k_ in slot}
         share = (slot or {}).get("issue_share", 0.0)
         if max(f_m, f_h) < 0.5 and share > max(f_m, f_h):
             roof.update({"bound": "valu_issue", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h,

@@ -1,5 +1,7 @@
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python tools/soak.py 40 16 1088 1920 2>&1 | tail -1
-python tools/soak.py 100 4 512 640 2>&1 | tail -1
-python tools/soak.py 100 3 704 1216 2>&1 | tail -1
-python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_r2_v4.json; cat gpurun_out/bench_r2_v4.json | cut -c1-600
+tools/pmc_profile.sh gpurun_out/r2_pmc_v4 gpurun_out/r2_pmc_v4.json > gpurun_out/pmc_profile.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2_v4_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-images 0 --other-configs 0 --no-single-rank-collective > $GRAFT_REPO_ROOT/gpurun_out/r2_v4_stats_bench.json 2> /dev/null
+cd $GRAFT_REPO_ROOT
+python bench.py 2>/dev/null | tail -1 > gpurun_out/r2_v4_bench.json
+cut -c1-400 gpurun_out/r2_v4_bench.json
+ls gpurun_out/r2_v4_stats/*/ | head

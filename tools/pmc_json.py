@@ -7,6 +7,9 @@ bench.py's hipEvent timing uses) the measured HBM bytes per launch and the issue
                          what a SIMD charges with >= 2 waves resident (tools/ubench/mfma_valu_mix.hip): 2.6 cycles per
                          wave64 VALU instruction, C = 12.5 per v_mfma_f32_16x16x32_f16 issued beside vector work (16
                          alone) or 32 per v_mfma_f32_16x16x4_f32 (no co-execution); GRBM_GUI_ACTIVE sums the 8 XCDs
+  valu_busy_share      = 4 * SQ_ACTIVE_INST_VALU / SIMD cycles,  mfma_busy_share = SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles:
+                         how long the SIMDs' two execution pipes were occupied; their sum is ~1.07 for the stage-1 kernels
+                         (the pipes overlap by a few per cent only: that sum is the roof these kernels sit under)
   wave_wait_share      = SQ_WAIT_ANY / SQ_WAVE_CYCLES       (parked at s_waitcnt / s_barrier)
   wave_issue_stall_share = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (an instruction ready, the pipe not)
 
@@ -25,7 +28,11 @@ def slot_of(kernel: str):
     k = kernel.replace("(anonymous namespace)::", "").replace("void ", "").replace("balf::", "").split("(")[0]
     m = re.match(r"stage1_kernel16<(\d)", k)
     if m:
-        return "stage1_%s_branch" % ("grid" if m.group(1) == "0" else "block")
+        return "stage1_pool" if m.group(1) == "2" else "stage1_%s_branch" % ("grid" if m.group(1) == "0" else "block")
+    m = re.match(r"stage_cs_kernel16<(\d+), \d+, (\d)>", k)
+    if m:
+        st = [32, 64, 128, 256].index(int(m.group(1))) + 1
+        return "stage%d_pool" % st if m.group(2) == "2" else "stage%d_%s_branch" % (st, "grid" if m.group(2) == "0" else "block")
     m = re.match(r"stage_branch_kernel(?:16)?(?:_ns)?<(\d+), \d+, (\d)>", k)
     if m:
         return "stage%d_%s_branch" % ([32, 64, 128, 256].index(int(m.group(1))) + 1, "grid" if m.group(2) == "0" else "block")
@@ -72,7 +79,10 @@ for prec in ("fp16", "fp32"):
                       "issue_share": (c["SQ_INSTS_VALU"] * 2.6 + c.get("SQ_INSTS_MFMA", 0.0) * mfma_cycles) / simd_cycles,
                       "wave_wait_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
                       "wave_issue_stall_share": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
-                      "valu_active_share": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                      # execution-pipe occupancy per SIMD cycle: the vector ALU (4 cycles per wave64 instruction, 16 per
+                      # transcendental; the counter is in quad-cycles) and the matrix pipe (16 cycles per 16x16x32 f16 MFMA)
+                      "valu_busy_share": 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles,
+                      "mfma_busy_share": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles,
                       "gpu_cycles": c["GRBM_GUI_ACTIVE"] / 8.0})
         slots[s] = d
     res[prec] = slots
