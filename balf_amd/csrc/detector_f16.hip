@@ -93,7 +93,7 @@ __device__ __forceinline__ void gemm16_chunk(f4 (&acc)[NTT][P], const float *w, 
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt)
 #pragma unroll
-            for (int p = 0; p < P; ++p) acc[NT0 + nt][p] = mfma16(a[nt].lo, b[p].hi, acc[NT0 + nt][p]);
+            for (int p = 0; p < P; ++p) if (!BALF_DROP_WLO) acc[NT0 + nt][p] = mfma16(a[nt].lo, b[p].hi, acc[NT0 + nt][p]);
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt)
 #pragma unroll
@@ -301,7 +301,7 @@ __device__ __forceinline__ void ring_mfma(f4 (&acc)[NTT][P], const HL (&a)[kRing
 #pragma unroll
     for (int nt = 0; nt < kRingNTC; ++nt)
 #pragma unroll
-        for (int p = 0; p < P; ++p) acc[CI * kRingNTC + nt][p] = mfma16(a[nt].lo, b[p].hi, acc[CI * kRingNTC + nt][p]);
+        for (int p = 0; p < P; ++p) if (!BALF_DROP_WLO) acc[CI * kRingNTC + nt][p] = mfma16(a[nt].lo, b[p].hi, acc[CI * kRingNTC + nt][p]);
 #pragma unroll
     for (int nt = 0; nt < kRingNTC; ++nt)
 #pragma unroll
@@ -378,7 +378,7 @@ __device__ __forceinline__ void gemm16_single(f4 (&acc)[2][P], const WPre &w, BL
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int p = 0; p < P; ++p) acc[nt][p] = mfma16(w.a[nt].lo, b[p].hi, acc[nt][p]);
+        for (int p = 0; p < P; ++p) if (!BALF_DROP_WLO) acc[nt][p] = mfma16(w.a[nt].lo, b[p].hi, acc[nt][p]);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -974,7 +974,7 @@ __device__ __forceinline__ void chain_chunk_ns(f4 (&acc)[NTL][P], const RingChai
 #pragma unroll
             for (int nt = 0; nt < HT; ++nt)
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[CI * HT + nt][p] = mfma16(a[nt].lo, b[p].hi, acc[CI * HT + nt][p]);
+                for (int p = 0; p < P; ++p) if (!BALF_DROP_WLO) acc[CI * HT + nt][p] = mfma16(a[nt].lo, b[p].hi, acc[CI * HT + nt][p]);
 #pragma unroll
             for (int nt = 0; nt < HT; ++nt)
 #pragma unroll
@@ -1520,7 +1520,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) f[t][p] = mfma16(a[t].lo, b[p].hi, f[t][p]);
+                for (int p = 0; p < 4; ++p) if (!BALF_DROP_WLO) f[t][p] = mfma16(a[t].lo, b[p].hi, f[t][p]);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll

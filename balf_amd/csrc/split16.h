@@ -28,6 +28,9 @@ __device__ __forceinline__ f4x mfma16(h8 a, h8 b, f4x c) {
 }
 
 // three-product accumulate: (ah + al)(bh + bl) ~ ah bh + al bh + ah bl
+#ifndef BALF_DROP_WLO
+#define BALF_DROP_WLO 0      // accuracy experiment: drop the (weight lo) x (activation hi) product of every Linear
+#endif
 __device__ __forceinline__ f4x mfma16x3(const HL &a, const HL &b, f4x c) {
     c = mfma16(a.lo, b.hi, c);
     c = mfma16(a.hi, b.lo, c);

@@ -129,7 +129,7 @@ __device__ __forceinline__ void s1_linear(f4 (&acc)[NT][P], const unsigned char 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int p = 0; p < P; ++p) acc[nt][p] = mfma16(a[nt].lo, b[p].hi, acc[nt][p]);
+        for (int p = 0; p < P; ++p) if (!BALF_DROP_WLO) acc[nt][p] = mfma16(a[nt].lo, b[p].hi, acc[nt][p]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll

@@ -100,7 +100,7 @@ __device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, con
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) acc[t][p] = mfma16(w.a[s][t].lo, b[p].hi, acc[t][p]);
+                for (int p = 0; p < 4; ++p) if (!BALF_DROP_WLO) acc[t][p] = mfma16(w.a[s][t].lo, b[p].hi, acc[t][p]);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -161,7 +161,7 @@ __device__ __forceinline__ void cs_linear_all(f4 (&acc)[2][4], const CsWAll<KSN>
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc[t][p] = mfma16(w.a[s][t].lo, b[p].hi, acc[t][p]);
+            for (int p = 0; p < 4; ++p) if (!BALF_DROP_WLO) acc[t][p] = mfma16(w.a[s][t].lo, b[p].hi, acc[t][p]);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -178,6 +178,9 @@ template <int C> constexpr int cs_tail_wps() { return C <= 64 ? 3 : 2; }
 template <int C, int CIN, int MODE>
 __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 2) void stage_cs_kernel16(StageArgs A) {
     constexpr int NW = cs_waves<C>(), KS = C / 32, KI = CIN / 32, NT = C / 16, P = 4;
+    constexpr int STAMP_KID = (C == 64 ? 1 : C == 128 ? 2 : 3) * 2 + (MODE & 1); (void)STAMP_KID;   // (diagnostic build only)
+    STAMPV_DECL;
+    STAMPV(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     h8 *bx = reinterpret_cast<h8 *>(smem_raw);                                            // shared B fragments
     unsigned char *btr = smem_raw + cs_bx_bytes<C>();                                      // token tiles, later u'
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
         }
     }
     if constexpr (!TAIL) barrier();                            // (tail: conv0 runs last, behind the barriers of the RCAB branch)
+    STAMPV(1);   // input staged
 
     struct Bias { f4 b[2]; };
     auto bias_load = [&](int off_floats) {                    // this wave's 32 channels of a bias vector (requested early)
@@ -349,6 +353,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
         bias_fill(x0, bias_load(S.conv0_b));
         cs_linear<KI>(x0, w, bl, w_c0, KI, from_bx, lane);
     }
+    STAMPV(2);   // conv0
     CsW wn;                                                    // the NEXT Linear's first fragments
     if constexpr (TAIL) {
         // ---- the stage's tail: x_next = maxpool2x2(x1 + x0 + s * conv2(lrelu(conv1(LN(x1))))) in fragment format ----
@@ -409,18 +414,22 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
     Bias bn = bias_load(S.q1_b + MODE * C);
     relu(x0);
     ln_publish(x0);
+    STAMPV(3);   // relu, LN exchange, publish
     // ---- z = GELU(dense1 half) ----
     f4 z[2][4];
     bias_fill(z, bn);
     cs_linear<KS>(z, wn, bl, w_q1, KS, from_bx, lane);
+    STAMPV(4);   // dense1 half
     cs_wload(wn, bl, w_d1a, KS, 0);
     bn = bias_load(Br.d1_b);
     gelu<false>(z);
     ln_publish(z);
+    STAMPV(5);   // GELU, LN exchange, publish
     // ---- branch dense1: a half, b half (same B operand) ----
     f4 ga[2][4];
     bias_fill(ga, bn);
     cs_linear<KS>(ga, wn, bl, w_d1a, KS, from_bx, lane);
+    STAMPV(6);   // branch dense1, a half
     cs_wload(wn, bl, w_d1b, KS, 0);
     bn = bias_load(Br.d1_b + C);
     gelu<false>(ga);
@@ -428,6 +437,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
         f4 gb[2][4];
         bias_fill(gb, bn);
         cs_linear<KS>(gb, wn, bl, w_d1b, KS, from_bx, lane);
+        STAMPV(7);   // GELU(a), b half
         cs_wload(wn, bl, w_d2, KS, 0);                             // dense2's first fragments travel through the token mix
         bn = bias_load(Br.d2_b);
         gelu<false>(gb);
@@ -451,6 +461,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
             }
         }
     }
+    STAMPV(8);   // GELU(b), gating LN exchange, token tile
     {   // token mix of this wave's 32 channels (wave-local) and the gate
         HL a[2][2];
 #pragma unroll
@@ -489,18 +500,23 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
             }
         }
     }
+    STAMPV(9);   // token mix + gate
     publish(bx, ga);                                           // every wave is past the gating-LN barrier: bx is free
     barrier();
     // ---- branch dense2 + residual ----
     f4 o[2][4];
     bias_fill(o, bn);
+    STAMPV(10);  // publish + barrier
     cs_linear<KS>(o, wn, bl, w_d2, KS, from_bx, lane);
+    STAMPV(11);  // dense2
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             f4 o0 = o[0][p] + z[0][p], o1 = o[1][p] + z[1][p];
             store_frag_px(A.U, pix0 + p * pstep, C, wave, q, split8(o0, o1));
         }
+        STAMPV(12);  // residual + u' store
+        STAMPV_FLUSH();
     } else {
         const unsigned w_q2 = wptr(S.q2_w, 0, 2 * KS, 0), w_r1 = wptr(S.r1_w, 0, KS, 0), w_r2 = wptr(S.r2_w, 0, KS, 0);
         // this wave's four u' fragments (of KS x 4): written by the grid kernel just before, served from L2 / the
@@ -530,6 +546,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
         // RSHMAG.dense2 over cat[u', v']: K-steps 0 .. KS-1 from the u' fragments, KS .. 2KS-1 from v'
         f4 x1[2][4];
         bias_fill(x1, bn);
+        STAMPV(12);  // u' loads, residual, barrier, publish v' + u', barrier
         cs_linear<2 * KS>(x1, wn, bl, w_q2, 2 * KS,
                           [&](int ks) { return ks < KS ? bu + ks * (4 * 2 * 64) : bx + (ks - KS) * (4 * 2 * 64); }, lane);
         cs_wload(wn, bl, w_r1, KS, 0);
@@ -544,10 +561,13 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
                 else
                     *reinterpret_cast<f4 *>(A.R + (pix0 + p * pstep) * C + c0 + 16 * nt + 4 * q) = x1[nt][p] + x0[nt][p];
             }
+        STAMPV(13);  // RSHMAG dense2, residual, x1 store
         ln_publish(x1);
+        STAMPV(14);  // LN exchange, publish
         f4 m1[2][4];
         bias_fill(m1, bn);
         cs_linear<KS>(m1, wn, bl, w_r1, KS, from_bx, lane);
+        STAMPV(15);  // conv1
         if constexpr (!cs_fused<C>()) {
             cs_wload(wn, bl, w_r2, KS, 0);
             bn = bias_load(S.r2_b);
@@ -580,5 +600,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
             for (int r = 0; r < 4; ++r) s[r] = row_ror_add<1>(row_ror_add<2>(row_ror_add<4>(row_ror_add<8>(s[r]))));
             if (li == 0) *reinterpret_cast<f4 *>(A.partial + (long)item * C + c0 + 16 * nt + 4 * q) = s;
         }
+        STAMPV(16);  // lrelu, (stage 4: exchange, conv2, T store), channel sums
+        STAMPV_FLUSH();
     }
 }

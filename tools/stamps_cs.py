@@ -1,6 +1,6 @@
 """Per-phase cycle breakdown of the channel-split stage kernels (diagnostic build libbalf_hip_stamps.so: -DBALF_STAMPS=1
--DBALF_S1_WAVE=0): wave 0 of every workgroup stamps s_memtime before and after every Linear and every barrier of its
-token group (the ids are the STAMP(i) points of stage_cs_f16.h, in program order)."""
+-DBALF_S1_WAVE=0): wave 0 of every workgroup stamps s_memtime between the phases of its token group (the STAMPV(i) points of
+stage_cs_f16.h, kept in a register per lane: no memory traffic between stamps), and every wave records the SIMD it runs on."""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, ".")
@@ -19,20 +19,15 @@ raw.balf_debug_stamps(sums, cnt, 1)
 for _ in range(2): m(x, want_logits=False)
 torch.cuda.synchronize()
 raw.balf_debug_stamps(sums, cnt, 0)
-common = ["", "in", "BAR", "pre", "conv0", "epi x0", "BAR", "pre", "q1", "epi z", "BAR", "pre", "d1b", "epi gb", "BAR", "tile+pre",
-          "d1a", "epi ga+mix+pub", "BAR", "pre", "d2"]
-grid = common + ["res+U"]
-block = common + ["u' req+res", "BAR", "pub v'+u'", "BAR", "pre", "q2", "res+R+pub x1", "BAR", "pre", "r1", "epi m1+pub", "BAR", "pre", "r2", "T+sums"]
+names = ["", "input staged", "conv0", "relu+LNx+pub", "dense1 half", "GELU+LNx+pub", "d1 a", "GELU(a)+d1 b", "GELU(b)+gLNx+tile", "mix+gate",
+         "pub+bar", "dense2", "res+U store | u'+res+bar+pub+bar", "q2+res+x1 store", "LNx+pub", "conv1", "lrelu(+xchg+conv2+T)+sums"]
 for kid in range(2, 8):
     n = cnt[kid]
     if not n: continue
-    names = block if kid % 2 else grid
     v = [sums[kid * NS + i] / n for i in range(NS)]
-    tot = sum(v[1:])
-    bar = sum(v[i] for i in range(1, len(names)) if names[i] == "BAR")
-    gemm = sum(v[i] for i in range(1, len(names)) if names[i] in ("conv0", "q1", "d1a", "d1b", "d2", "q2", "r1", "r2"))
-    print(f"C={[32,64,128,256][kid//2]} {'block' if kid%2 else 'grid'}: {n} groups, {tot:8.0f} cycles/group (barrier waits {bar:.0f}, Linears {gemm:.0f}):  " +
-          "  ".join(f"{names[i]}={v[i]:.0f}" for i in range(1, len(names))))
+    tot = sum(v[1:len(names)])
+    print(f"C={[32,64,128,256][kid//2]} {'block' if kid%2 else 'grid'}: {n} groups, {tot:8.0f} cycles/group:  " +
+          "  ".join(f"{names[i]}={v[i]:.0f}" for i in range(1, len(names)) if v[i]))
 for kid in range(2, 8):
     if cnt[kid]:
         print(f"kid {kid}: SIMD of wave slot w (rows) : " + " | ".join(" ".join(str(sums[(8 + kid) * NS + w * 4 + sd]) for sd in range(4)) for w in range(8)))
