@@ -66,5 +66,10 @@ int main() {
     run<32, 8, 1>(out);
     run<64, 8, 1>(out);
     run<32, 4, 1>(out);
+    // the shape of a Linear + epilogue in the stage kernels: 24 MFMAs and 3 / 6 vector instructions per MFMA
+    run<72, 24, 0>(out);
+    run<72, 24, 1>(out);
+    run<144, 24, 0>(out);
+    run<144, 24, 1>(out);
     return 0;
 }
