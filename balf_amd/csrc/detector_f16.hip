@@ -1662,7 +1662,8 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
         // channel-split kernels: one workgroup of C/32 waves per token group, no weight ring
         auto c0k = stage_cs_kernel16<C, CIN, 0>;
         auto c1k = stage_cs_kernel16<C, CIN, 1>;
-        constexpr int clds = cs_lds_bytes<C>();
+        constexpr int G = cs_groups<C>();
+        constexpr int clds = cs_lds_bytes<C>() * G;
         static_assert(clds <= 160 * 1024, "channel-split LDS image");
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(c0k), hipFuncAttributeMaxDynamicSharedMemorySize, clds) !=
                 hipSuccess ||
@@ -1671,8 +1672,9 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
             return BALF_ERR_LAUNCH;
         per_img = (H / 8) * (W / 8);                       // one partial-sum row per token group
         const unsigned groups = (unsigned)((long)B * per_img);
-        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(c0k, dim3(groups), dim3(cs_waves<C>() * 64), clds, st, a));
-        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(c1k, dim3(groups), dim3(cs_waves<C>() * 64), clds, st, a));
+        if (groups % G != 0) return BALF_ERR_ARG;              // (H, W multiples of 64: per_img is a multiple of 4 at C <= 128)
+        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(c0k, dim3(groups / G), dim3(cs_waves<C>() * G * 64), clds, st, a));
+        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(c1k, dim3(groups / G), dim3(cs_waves<C>() * G * 64), clds, st, a));
     } else if constexpr ((C == 256 && BALF_NS256 != 0) || (C == 128 && BALF_NS128 != 0) || (C == 64 && BALF_NS64 != 0)) {
         constexpr int nlds = ns_lds_bytes<C>();
         static_assert(nlds <= (C >= 256 ? 160 : 80) * 1024, "N-split LDS image");
@@ -1718,11 +1720,13 @@ int run_tail_cs16(const float *blob, int s, const float *X, const float *R, cons
                   hipStream_t st) {
     StageArgs a{blob, kLayout.st[s], X, nullptr, 0, 0, 0, 0, 0, B, H, W, nullptr, nullptr, const_cast<float *>(R), nullptr, scale, out};
     auto k = stage_cs_kernel16<C, CIN, 2>;
-    constexpr int clds = cs_tail_lds_bytes<C>();
+    constexpr int G = cs_groups<C>();
+    constexpr int clds = cs_tail_lds_bytes<C>() * G;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, clds) != hipSuccess)
         return BALF_ERR_LAUNCH;
     const unsigned groups = (unsigned)((long)B * (H / 8) * (W / 8));
-    BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(k, dim3(groups), dim3(cs_waves<C>() * 64), clds, st, a));
+    if (groups % G != 0) return BALF_ERR_ARG;
+    BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(k, dim3(groups / G), dim3(cs_waves<C>() * G * 64), clds, st, a));
     BALF_LAUNCH_CHECK();
     return BALF_OK;
 }

@@ -469,11 +469,12 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
                     }
             // both lanes of a row pair hold the same two pooled pixels: lane li stores pooled column 2 (li & 1) + ((li >> 1) & 1)
             const int sel = (li >> 1) & 1;
+            const unsigned selm = 0u - (unsigned)sel;          // all ones in the lanes that take the second column (v_bfi, not v_cndmask)
             f4 o0, o1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                o0[r] = sel ? mx[0][1][r] : mx[0][0][r];
-                o1[r] = sel ? mx[1][1][r] : mx[1][0][r];
+                o0[r] = lane_select(selm, mx[0][1][r], mx[0][0][r]);
+                o1[r] = lane_select(selm, mx[1][1][r], mx[1][0][r]);
             }
             const long opix = ((long)g.n * (H / 2) + (g.y >> 1)) * (W / 2) + (g.x0 >> 1) + sel;
             store_frag_px(A.out, opix, C, 0, q, split8(o0, o1));

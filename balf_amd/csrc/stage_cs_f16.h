@@ -173,15 +173,23 @@ __device__ __forceinline__ void cs_linear_all(f4 (&acc)[2][4], const CsWAll<KSN>
     }
 }
 
+#ifndef BALF_CS_G
+#define BALF_CS_G 1          // token groups per workgroup at C <= 128 (2: the paired waves of the two groups request the same weight lines in step)
+#endif
+template <int C> constexpr int cs_groups() { return C <= 128 ? BALF_CS_G : 1; }
 // waves per SIMD the tail kernels are compiled for: 3 at C = 64 (156 registers), 2 at C = 128 (two Linears' tiles in flight)
 template <int C> constexpr int cs_tail_wps() { return C <= 64 ? 3 : 2; }
 template <int C, int CIN, int MODE>
-__global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 2) void stage_cs_kernel16(StageArgs A) {
-    constexpr int NW = cs_waves<C>(), KS = C / 32, KI = CIN / 32, NT = C / 16, P = 4;
+__global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 2) void stage_cs_kernel16(StageArgs A) {
+    constexpr int NW = cs_waves<C>(), KS = C / 32, KI = CIN / 32, NT = C / 16, P = 4, G = cs_groups<C>();
     constexpr int STAMP_KID = (C == 64 ? 1 : C == 128 ? 2 : 3) * 2 + (MODE & 1); (void)STAMP_KID;   // (diagnostic build only)
     STAMPV_DECL;
     STAMPV(0);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    // (G = 2) two token groups per workgroup, each with its own LDS image and its own waves; they share the barriers only
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = (G == 1) ? 0 : wave_all / NW;
+    unsigned char *smem_raw = smem_all + grp * (MODE == 2 ? cs_tail_lds_bytes<C>() : cs_lds_bytes<C>());
     h8 *bx = reinterpret_cast<h8 *>(smem_raw);                                            // shared B fragments
     unsigned char *btr = smem_raw + cs_bx_bytes<C>();                                      // token tiles, later u'
     h8 *bu = reinterpret_cast<h8 *>(btr);
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
     // the stage input's fragments: in bx (conv0 is the first Linear), or (tail) in a region of their own behind the statistics
     h8 *bxin = (MODE == 2) ? reinterpret_cast<h8 *>(smem_raw + cs_bx_bytes<C>() + cs_waves<C>() * 4 * 16 * 8) : bx;
     const int lane = threadIdx.x & 63, q = lane >> 4, li = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave_all - grp * NW;
     _Float16 *bT = reinterpret_cast<_Float16 *>(btr + wave * kS1BtBytes);
     const float *blob = A.blob;
     const StageOff &S = A.off;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
     // XCD-aware group order (speed only), as in the ring kernels
     const int nwg = gridDim.x;
     const int xq = nwg >> 3, xr = nwg & 7, xl = blockIdx.x & 7, xj = blockIdx.x >> 3;
-    const int item = (xl < xr ? xl * (xq + 1) : xr * (xq + 1) + (xl - xr) * xq) + xj;
+    const int item = ((xl < xr ? xl * (xq + 1) : xr * (xq + 1) + (xl - xr) * xq) + xj) * G + grp;
     const int n = item / per_img, rem = item - n * per_img;
     const int gy = rem / fw, gx = rem - gy * fw;
     const int ty = li >> 1, tx0 = 4 * (li & 1);
@@ -240,6 +248,7 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
             xin[f] = load_frag_px(A.X, pix0 + p * pstep, CIN, kk, q);
         }
         if constexpr (cs_mix_in_lds<C>()) {
+            static_assert(!cs_mix_in_lds<C>() || G == 1, "the LDS copy of the mixing matrix is per workgroup");
             for (int i = threadIdx.x; i < 8 * 2 * 64; i += NW * 64) {
                 const int l = i & 63, part = (i >> 6) & 1, tile = i >> 7, pt = tile >> 1, ks = tile & 1;
                 const int g = 4 * (l & 15) + pt;
@@ -400,11 +409,12 @@ __global__ __launch_bounds__(cs_waves<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 
                 }
         // both lanes of a row pair hold the same two pooled pixels: lane li stores pooled column 2 (li & 1) + ((li >> 1) & 1)
         const int sel = (li >> 1) & 1;
+        const unsigned selm = 0u - (unsigned)sel;              // all ones in the lanes that take the second column (v_bfi, not v_cndmask)
         f4 o0, o1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            o0[r] = sel ? mx[0][1][r] : mx[0][0][r];
-            o1[r] = sel ? mx[1][1][r] : mx[1][0][r];
+            o0[r] = lane_select(selm, mx[0][1][r], mx[0][0][r]);
+            o1[r] = lane_select(selm, mx[1][1][r], mx[1][0][r]);
         }
         const long opix = ((long)n * (H / 2) + (y >> 1)) * (W / 2) + (xl0 >> 1) + sel;
         store_frag_px(A.out, opix, C, wave, q, split8(o0, o1));

@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_issue.hip -o /tmp/valu_issue && /tmp/valu_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef float f4x __attribute__((ext_vector_type(4)));
@@ -55,6 +56,37 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, in
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pk[(4 * j + i) & 7]) : "v"(m2), "v"(c2));
             }
+        } else if (MODE >= 7) {    // 32 independent instructions of another class (which of them run at the fma's rate?)
+            unsigned *u = reinterpret_cast<unsigned *>(a);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (MODE == 7) asm volatile("v_max_i32 %0, %0, %1" : "+v"(u[i]) : "v"(7));
+                    if (MODE == 8) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                    if (MODE == 9) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(u[i]) : "v"(u[(i + 1) & 15]));
+                    if (MODE == 10) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(m));
+                    if (MODE == 11) asm volatile("v_and_b32 %0, %0, %1" : "+v"(u[i]) : "v"(0x7fffffffu));
+                    if (MODE == 12) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                    if (MODE == 13) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                    if (MODE == 14) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                    if (MODE == 15) asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+                    if (MODE == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[(i + 8) & 15]));
+                    if (MODE == 17) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m));
+                    if (MODE == 18) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                    if (MODE == 19) asm volatile("v_fma_f32 %0, |%0|, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                    if (MODE == 20) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                    if (MODE == 21) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(a[i]));
+                    if (MODE == 22) asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                    if (MODE == 23) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(m), "v"(0x07060302u));
+                    if (MODE == 24) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(u[i]) : "v"(0xffff0000u), "v"(m));
+                    if (MODE == 25) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a[i]));
+                    if (MODE == 26) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(m));
+                    if (MODE == 27) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[0,0,0]" : "+v"(a[i]) : "v"(m), "v"(c));
+                    if (MODE == 28) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                    if (MODE == 29) asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(u[i]));
+                    if (MODE == 30) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                }
         } else if (MODE == 6) {    // 32 dependent-free v_fma_f32 in 4 chains of dependent ops (latency)
 #pragma unroll
             for (int r = 0; r < 8; ++r)
@@ -77,7 +109,7 @@ void run(const char *name, int per_iter_valu, int per_iter_mfma) {
     float *out; unsigned long long *cyc;
     const int maxb = 256 * 8;
     hipMalloc(&out, maxb * 256 * 4); hipMalloc(&cyc, maxb * 4 * 8);
-    for (int w : {1, 2, 3, 4, 6, 8}) {
+    for (int w : {2, 4}) {
         const int blocks = 256 * w;
         hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, cyc, 10);
         hipDeviceSynchronize();
@@ -100,6 +132,34 @@ void run(const char *name, int per_iter_valu, int per_iter_mfma) {
 }
 
 int main() {
+    if (getenv("VALU_CLASSES")) {
+        run<0>("v_fma_f32 x32", 32, 0);
+        run<7>("v_max_i32 x32", 32, 0);
+        run<8>("v_cvt_pkrtz_f16_f32 x32", 32, 0);
+        run<9>("v_fma_mixlo_f16 x32", 32, 0);
+        run<10>("v_mov_b32 x32", 32, 0);
+        run<11>("v_and_b32 x32", 32, 0);
+        run<12>("v_add_f32 x32", 32, 0);
+        run<13>("v_mul_f32 x32", 32, 0);
+        run<14>("v_max_f32 x32", 32, 0);
+        run<15>("v_add_f32 dpp row_ror x32", 32, 0);
+        run<16>("s_nop 1 + v_permlane16_swap x32", 32, 0);
+        run<17>("v_cndmask_b32 x32", 32, 0);
+        run<18>("v_fmac_f32 x32", 32, 0);
+        run<19>("v_fma_f32 |src| x32", 32, 0);
+        run<20>("v_cvt_pk_f16_f32 x32", 32, 0);
+        run<21>("v_cvt_f16_f32 x32", 32, 0);
+        run<22>("v_pack_b32_f16 x32", 32, 0);
+        run<23>("v_perm_b32 x32", 32, 0);
+        run<24>("v_bfi_b32 x32", 32, 0);
+        run<25>("v_cvt_f32_f16 x32", 32, 0);
+        run<26>("v_med3_f32 x32", 32, 0);
+        run<27>("v_fma_mix_f32 x32", 32, 0);
+        run<28>("v_sub_f32 x32", 32, 0);
+        run<29>("v_lshlrev_b32 x32", 32, 0);
+        run<30>("v_cvt_pk_bf16_f32 x32", 32, 0);
+        return 0;
+    }
     run<0>("v_fma_f32 x32", 32, 0);
     run<1>("v_pk_fma_f32 x32", 32, 0);
     run<2>("v_exp_f32 x32", 32, 0);
