@@ -14,7 +14,8 @@
 //     MFMA (split8), no LDS round trip;
 //   * all weights of the stage (36 KB grid / 52 KB block, split-f16 fragments) fit in LDS next to the token tiles:
 //     they are staged ONCE per workgroup and the workgroup is persistent (one per CU, waves loop over groups), so
-//     no weight ever comes from L2 inside the loop; conv0 (3 -> 32) runs on the matrix pipe too (K padded to 32).
+//     no weight ever comes from L2 inside the loop; conv0 (3 -> 32) runs on the matrix pipe too, as eight exact-fp32
+//     v_mfma_f32_16x16x4_f32 (K = 3 padded to 4: lane quarter q feeds input channel q, no operand split).
 // Token t = 8 ty + tx of a group sits in MFMA column li of pixel tile p with t = 4 li + p: a lane's four tiles are
 // four ADJACENT tokens, so the transposed tile is written with 8-byte LDS stores and (block branch) the NCHW input
 // is read with one 16-byte load per colour plane.  The mixing matrix is re-ordered to that column order when it is
@@ -22,8 +23,14 @@
 #pragma once
 
 constexpr int kS1C = 32;
-constexpr int kS1Pitch = 72;                                   // halves per channel row of the transposed token tile
-constexpr int kS1BtBytes = 2 * kS1C * kS1Pitch * 2;            // hi + lo planes per wave: 9216 B
+// Transposed token tile of a wave (32 channels x 64 tokens, hi and lo planes of 4 KB): rows of 128 B whose eight 16-B
+// chunks are XOR-swizzled by the row, so that the 8-byte writes (a lane's four adjacent tokens of one channel) and the
+// 16-byte A-fragment reads (eight tokens of a row) both spread over the LDS banks without padding.
+constexpr int kS1BtPlane = kS1C * 128;
+constexpr int kS1BtBytes = 2 * kS1BtPlane;                     // 8192 B per wave
+// byte offset of tokens 4 li .. 4 li + 3 of channel row c (writer) / of tokens 8 j .. 8 j + 7 of row c (reader)
+__device__ __forceinline__ int s1_bt_wr(int c, int li) { return c * 128 + (((li >> 1) ^ (c & 7)) << 4) + (li & 1) * 8; }
+__device__ __forceinline__ int s1_bt_rd(int c, int j) { return c * 128 + ((j ^ (c & 7)) << 4); }
 // LDS image: weight tiles (2 KiB each: [hi 64 x 16 B][lo 64 x 16 B]) ...
 constexpr int kS1Conv0 = 0;                                    // 2 row tiles (built in the kernel from the plain [32,3] matrix)
 constexpr int kS1Q1 = kS1Conv0 + 2 * 2048;                     // 2 row tiles (this branch's half of RSHMAG.dense1)
@@ -156,7 +163,7 @@ __device__ __forceinline__ void s1_bias(f4 (&t)[NT][P], const float *par, int q)
 // LOAD of the loop is inline asm with a counted wait placed by hand (the compiler, seeing only stores, never waits):
 //   top of group i:   wait for the input pixels of group i       (younger operations: the stores of group i-1 -> vmcnt(8))
 //                     issue the u' rows of group i (block branch), then the input pixels of group i+1
-//   before RSHMAG.dense2 (block): wait for the u' rows          (younger: the 3 input loads -> vmcnt(3))
+//   before RSHMAG.dense2 (block): wait for the u' rows          (younger: the input load -> vmcnt(1))
 // The loads of the last group's successor are issued anyway (clamped to a valid group) so that the counts are static.
 // a wave-uniform pointer as a scalar-register pair (hipcc does 64-bit multiplies of uniform values on the vector unit
 // and then hands the asm's "s" operand a VGPR pair)
@@ -178,7 +185,7 @@ __device__ __forceinline__ const T *uniform_ptr(const T *p) {
 #define BALF_S1_WAIT_U "s_waitcnt vmcnt(0)"
 #else
 #define BALF_S1_WAIT_IN "s_waitcnt vmcnt(8)"
-#define BALF_S1_WAIT_U "s_waitcnt vmcnt(3)"
+#define BALF_S1_WAIT_U "s_waitcnt vmcnt(1)"
 #endif
 template <int MODE, bool U8>
 __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(StageArgs A) {
@@ -219,20 +226,12 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             *reinterpret_cast<uint4 *>(smem_raw + kS1Mix + tile * 2048 + part * 1024 + l * 16) =
                 *reinterpret_cast<const uint4 *>(s);
         }
-        // conv0 [32, 3] as A fragments with K padded to 32: input channel c in k-slot (q = 0, j = c)
+        // conv0 [32, 3] as A fragments of v_mfma_f32_16x16x4_f32 (exact fp32, K = 3 padded to 4): lane (li, q) holds
+        // W[16 nt + li][q] (q < 3)
         for (int i = threadIdx.x; i < 2 * 64; i += NTHR) {
-            const int l = i & 63, nt = i >> 6;
-            h8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
-            if ((l >> 4) == 0) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float w = blob[S.conv0_w + (16 * nt + (l & 15)) * 3 + j];
-                    hi[j] = (_Float16)w;
-                    lo[j] = (_Float16)(w - (float)hi[j]);
-                }
-            }
-            *reinterpret_cast<h8 *>(smem_raw + kS1Conv0 + nt * 2048 + l * 16) = hi;
-            *reinterpret_cast<h8 *>(smem_raw + kS1Conv0 + nt * 2048 + 1024 + l * 16) = lo;
+            const int l = i & 63, nt = i >> 6, k = l >> 4;
+            *reinterpret_cast<float *>(smem_raw + kS1Conv0 + nt * 256 + l * 4) =
+                k < 3 ? blob[S.conv0_w + (16 * nt + (l & 15)) * 3 + k] : 0.0f;
         }
         for (int i = threadIdx.x; i < kS1ParFloats; i += NTHR) {
             float v;
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         __syncthreads();                                         // the only barrier of the kernel
     }
 
-    _Float16 *bT = reinterpret_cast<_Float16 *>(smem_raw + s1_weight_bytes<MODE>() + kS1ParFloats * 4 + wave * kS1BtBytes);
+    unsigned char *bT = smem_raw + s1_weight_bytes<MODE>() + kS1ParFloats * 4 + wave * kS1BtBytes;
     const unsigned char *wl = smem_raw + lane * 16;              // weight fragments: + region + tile * 2048 (+ 1024: lo)
 
     const int H = A.H, W = A.W, fh = H / 8, fw = W / 8;
@@ -290,38 +289,34 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         g.pix0 = ((long)g.n * H + g.y) * W + g.x0;
         return g;
     };
-    // raw network input of the lane's four pixels (lanes q = 0 only: k-slots q = 0, j = 0..2 of conv0's B operand):
-    // float bits, or (U8) the uint8 value, 0x100 = outside the image: zero padding
-    auto load_raw_u8 = [&](const Geo &g, unsigned (&raw)[P][3]) {
-        if (q != 0) return;
+    // raw network input of the lane's four pixels: lane quarter q holds input channel q (conv0's B operand: k = q; the
+    // fourth quarter is the zero padding of K) -- float bits, or (U8) the uint8 value, 0x100 = outside the image
+    const int cq = q < 3 ? q : 2;
+    auto load_raw_u8 = [&](const Geo &g, unsigned (&raw)[P]) {
+        if (q >= 3) return;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int yy = g.y - A.u8_top, xx = g.x0 + p * pstep - A.u8_left;
             const bool ok = yy >= 0 && yy < A.u8_h && xx >= 0 && xx < A.u8_w;
             const unsigned char *px8 = A.X8 + (((long)g.n * A.u8_h + (ok ? yy : 0)) * A.u8_w + (ok ? xx : 0)) * A.u8_ch;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) raw[p][k] = ok ? (unsigned)px8[A.u8_ch == 3 ? k : 0] : 0x100u;
+            raw[p] = ok ? (unsigned)px8[A.u8_ch == 3 ? cq : 0] : 0x100u;
         }
     };
     const int hw = H * W;                                       // (32-bit: keeps the plane offsets on the scalar unit)
-    // float input, asm loads (not counted by the compiler): plane k of image n at a scalar base, the lane's pixel offset
-    // in a VGPR.  Lanes q != 0 are masked off and keep the zeros `raw` starts with.
-    auto issue_raw = [&](const Geo &g, unsigned (&raw)[P][3], f4 (&rawv)[3]) {
-        const unsigned voff = (unsigned)(g.y * W + g.x0) * 4u;
-        const float *xb = A.X + (long)g.n * 3 * (long)hw;
-        const float *x0p = uniform_ptr(xb), *x1p = uniform_ptr(xb + hw), *x2p = uniform_ptr(xb + 2 * hw);
-        if (q == 0) {
+    // float input, asm loads (not counted by the compiler): the image's planes at a scalar base, the lane's plane and pixel
+    // offset in a VGPR.  Lanes q = 3 are masked off and keep the zeros `raw` starts with.
+    const unsigned qoff = (unsigned)(cq * hw) * 4u;
+    auto issue_raw = [&](const Geo &g, unsigned (&raw)[P], f4 &rawv) {
+        const unsigned voff = (unsigned)(g.y * W + g.x0) * 4u + qoff;
+        const float *xb = uniform_ptr(A.X + (long)g.n * 3 * (long)hw);
+        if (q < 3) {
             if constexpr (BM == 1) {
-                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %5\n\t"
-                             "global_load_dwordx4 %2, %3, %6"
-                             : "+v"(rawv[0]), "+v"(rawv[1]), "+v"(rawv[2]) : "v"(voff), "s"(x0p), "s"(x1p), "s"(x2p) : "memory");
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(rawv) : "v"(voff), "s"(xb) : "memory");
             } else {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const unsigned vp = voff + (unsigned)(p * pstep) * 4u;
-                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %3, %4\n\tglobal_load_dword %1, %3, %5\n\t"
-                                 "global_load_dword %2, %3, %6"
-                                 : "+v"(raw[p][0]), "+v"(raw[p][1]), "+v"(raw[p][2]) : "v"(vp), "s"(x0p), "s"(x1p), "s"(x2p) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(raw[p]) : "v"(vp), "s"(xb) : "memory");
                 }
             }
         }
@@ -341,19 +336,19 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     };
     int item = xcd * nx + wx;                                    // wave-uniform
     Pos nxt = decompose(item);
-    unsigned raw[P][3] = {};
-    f4 rawv[3] = {};
+    unsigned raw[P] = {};
+    f4 rawv = {};
     if (!U8 && !TAIL && item < total) {
         issue_raw(geo(nxt), raw, rawv);
         // the first group has no older stores in front of its pixels: drain (the counted wait in the loop assumes them)
         if constexpr (MODE == 1)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawv[0]), "+v"(rawv[1]), "+v"(rawv[2]) :: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawv) :: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[1][0]), "+v"(raw[1][1]),
-                           "+v"(raw[1][2]), "+v"(raw[2][0]), "+v"(raw[2][1]), "+v"(raw[2][2]), "+v"(raw[3][0]),
-                           "+v"(raw[3][1]), "+v"(raw[3][2]) :: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) :: "memory");
     }
+    float a0[2];                                                 // conv0's A fragments (loop-invariant)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) a0[nt] = *reinterpret_cast<const float *>(smem_raw + kS1Conv0 + nt * 256 + lane * 4);
 
     for (; item < total; item += stride) {
         const Geo g = geo(nxt);
@@ -365,11 +360,8 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         f4 x1t[TAIL ? 2 : 1][TAIL ? P : 1], sct[2];
         if constexpr (TAIL) {
             if constexpr (!U8) {
-                if (q == 0) {
-                    const float *xb = A.X + (long)g.n * 3 * (long)hw + (long)g.y * W + g.x0;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) rawv[k] = *reinterpret_cast<const f4 *>(xb + (long)k * hw);
-                }
+                if (q < 3)
+                    rawv = *reinterpret_cast<const f4 *>(A.X + ((long)g.n * 3 + cq) * (long)hw + (long)g.y * W + g.x0);
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -380,34 +372,20 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             }
         }
         STAMP(0);
-        HL bx[P];                                                // conv0's B fragments
+        float bx[P];                                             // conv0's B fragments: the lane's channel of its four pixels
         {
             if constexpr (!U8 && !TAIL) {
                 // the input pixels of this group have landed; the previous group's stores may still be in flight
                 if constexpr (MODE == 1)
-                    asm volatile(BALF_S1_WAIT_IN : "+v"(rawv[0]), "+v"(rawv[1]), "+v"(rawv[2]) :: "memory");
+                    asm volatile(BALF_S1_WAIT_IN : "+v"(rawv) :: "memory");
                 else
-                    asm volatile(BALF_S1_WAIT_IN
-                                 : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[1][0]), "+v"(raw[1][1]),
-                                   "+v"(raw[1][2]), "+v"(raw[2][0]), "+v"(raw[2][1]), "+v"(raw[2][2]), "+v"(raw[3][0]),
-                                   "+v"(raw[3][1]), "+v"(raw[3][2]) :: "memory");
+                    asm volatile(BALF_S1_WAIT_IN : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) :: "memory");
             }
-            float in[P][3];
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    if (U8) in[p][k] = (q == 0 && raw[p][k] < 256u) ? par[kS1pLut + (raw[p][k] & 255u)] : 0.0f;
-                    else if (BM == 1) in[p][k] = rawv[k][p];
-                    else in[p][k] = __builtin_bit_cast(float, raw[p][k]);
-                }
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                h2 h01, l01, h2x, l2x;
-                split_pair(in[p][0], in[p][1], h01, l01);
-                split_pair(in[p][2], 0.0f, h2x, l2x);
-                bx[p].hi = h8{h01[0], h01[1], h2x[0], 0, 0, 0, 0, 0};
-                bx[p].lo = h8{l01[0], l01[1], l2x[0], 0, 0, 0, 0, 0};
+                if (U8) bx[p] = (q < 3 && raw[p] < 256u) ? par[kS1pLut + (raw[p] & 255u)] : 0.0f;
+                else if (BM == 1) bx[p] = rawv[p];
+                else bx[p] = __builtin_bit_cast(float, raw[p]);
             }
         }
         HL ub[(MODE == 1) ? P : 1];                              // block: u' rows of the lane's pixels (pre-split in HBM)
@@ -425,11 +403,14 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
 #undef BALF_S1_UB
             }
         }
-        if constexpr (!U8 && !TAIL) issue_raw(geo(nxt), raw, rawv);   // next group's pixels (12 or 3 loads, always)
+        if constexpr (!U8 && !TAIL) issue_raw(geo(nxt), raw, rawv);   // next group's pixels (4 loads or 1, always)
         STAMP(1);   // input -> conv0 B fragments (waits for the prefetched pixels), next group's loads issued
         auto conv0 = [&](f4 (&x0v)[2][P]) {                      // x0 = relu(conv0(X)); bit-identical every time
             s1_bias(x0v, par + kS1pConv0B, q);
-            s1_linear(x0v, wl + kS1Conv0, 2048, bx);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int p = 0; p < P; ++p) x0v[nt][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nt], bx[p], x0v[nt][p], 0, 0, 0);
             relu(x0v);
         };
 
@@ -520,9 +501,9 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
                     split_pair(v[0], v[1], h01, l01);
                     split_pair(v[2], v[3], h23, l23);
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                    _Float16 *row = bT + (16 * nt + 4 * q + r) * kS1Pitch + 4 * li;
+                    unsigned char *row = bT + s1_bt_wr(16 * nt + 4 * q + r, li);
                     *reinterpret_cast<h4 *>(row) = h4{h01[0], h01[1], h23[0], h23[1]};
-                    *reinterpret_cast<h4 *>(row + C * kS1Pitch) = h4{l01[0], l01[1], l23[0], l23[1]};
+                    *reinterpret_cast<h4 *>(row + kS1BtPlane) = h4{l01[0], l01[1], l23[0], l23[1]};
                 }
             }
         }
@@ -534,9 +515,9 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    const _Float16 *row = bT + (16 * ct + li) * kS1Pitch + 32 * kk + 8 * q;
+                    const unsigned char *row = bT + s1_bt_rd(16 * ct + li, 4 * kk + q);
                     a[ct][kk].hi = *reinterpret_cast<const h8 *>(row);
-                    a[ct][kk].lo = *reinterpret_cast<const h8 *>(row + C * kS1Pitch);
+                    a[ct][kk].lo = *reinterpret_cast<const h8 *>(row + kS1BtPlane);
                 }
             const f4 mb1 = *reinterpret_cast<const f4 *>(par + kS1pMixB1 + 4 * li);
 #pragma unroll
@@ -575,7 +556,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             f4 x1[2][P];
             s1_bias(x1, par + kS1pQ2B, q);
             s1_linear(x1, wl + kS1Q2 + 2048, 2 * 2048, b);       // K-step 1 = v' half of cat[u', v']
-            if constexpr (!U8)                                   // u' rows have landed (younger: next group's 3 input loads)
+            if constexpr (!U8)                                   // u' rows have landed (younger: next group's input load)
                 asm volatile(BALF_S1_WAIT_U
                              : "+v"(ub[0].hi), "+v"(ub[0].lo), "+v"(ub[1].hi), "+v"(ub[1].lo), "+v"(ub[2].hi), "+v"(ub[2].lo),
                                "+v"(ub[3].hi), "+v"(ub[3].lo) :: "memory");

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
     h8 *bxin = (MODE == 2) ? reinterpret_cast<h8 *>(smem_raw + cs_bx_bytes<C>() + cs_waves<C>() * 4 * 16 * 8) : bx;
     const int lane = threadIdx.x & 63, q = lane >> 4, li = lane & 15;
     const int wave = wave_all - grp * NW;
-    _Float16 *bT = reinterpret_cast<_Float16 *>(btr + wave * kS1BtBytes);
+    unsigned char *bT = btr + wave * kS1BtBytes;
     const float *blob = A.blob;
     const StageOff &S = A.off;
     const BranchOff &Br = S.br[MODE == 0 ? 0 : 1];
@@ -465,9 +465,9 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
                 split_pair(v[0], v[1], h01, l01);
                 split_pair(v[2], v[3], h23, l23);
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                _Float16 *row = bT + (16 * nt + 4 * q + r) * kS1Pitch + 4 * li;
+                unsigned char *row = bT + s1_bt_wr(16 * nt + 4 * q + r, li);
                 *reinterpret_cast<h4 *>(row) = h4{h01[0], h01[1], h23[0], h23[1]};
-                *reinterpret_cast<h4 *>(row + kS1C * kS1Pitch) = h4{l01[0], l01[1], l23[0], l23[1]};
+                *reinterpret_cast<h4 *>(row + kS1BtPlane) = h4{l01[0], l01[1], l23[0], l23[1]};
             }
         }
     }
@@ -478,9 +478,9 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const _Float16 *row = bT + (16 * ct + li) * kS1Pitch + 32 * kk + 8 * q;
+                const unsigned char *row = bT + s1_bt_rd(16 * ct + li, 4 * kk + q);
                 a[ct][kk].hi = *reinterpret_cast<const h8 *>(row);
-                a[ct][kk].lo = *reinterpret_cast<const h8 *>(row + kS1C * kS1Pitch);
+                a[ct][kk].lo = *reinterpret_cast<const h8 *>(row + kS1BtPlane);
             }
         const f4 mbv = CsBlob{bl.rsrc, (unsigned)li * 16u}.vec((unsigned)Br.mix_b * 4u);
 #pragma unroll
