@@ -1,0 +1,58 @@
+"""Invariants of the BUILT library that the source cannot express (no GPU needed): read the gfx950 code objects out of
+libbalf_hip.so and check kernel metadata.
+
+The float-input stage-1 kernels issue their loads from inline asm with hand-counted `s_waitcnt vmcnt(N)` (stage1_f16.h:
+the compiler would otherwise drain the store queue at every loop back edge).  Scratch traffic is vector-memory traffic:
+a register spill inside that loop shifts every count and the kernel computes on data that has not arrived (seen when
+the block kernel was forced to 168 registers).  So those kernels must not spill."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from balf_amd import _lib
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _kernel_metadata(tmp_path):
+    for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"):
+        if not os.path.exists(os.path.join(LLVM, t)):
+            pytest.skip(f"{t} not available")
+    so = _lib.LIB_PATH
+    fat = tmp_path / "fat.bin"
+    subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", so], check=True)
+    blob = fat.read_bytes()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    assert starts, "no offload bundle in .hip_fatbin"
+    meta = {}
+    for i, a in enumerate(starts):
+        b = starts[i + 1] if i + 1 < len(starts) else len(blob)
+        part, co = tmp_path / f"bundle{i}.bin", tmp_path / f"bundle{i}.co"
+        part.write_bytes(blob[a:b])
+        subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", notes, re.S):
+            meta[m.group(1)] = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|private_segment_fixed_size):\s+(\d+)", m.group(2))}
+    return meta
+
+
+def test_asm_load_kernels_do_not_spill(tmp_path):
+    if shutil.which("c++filt") is None:
+        pytest.skip("c++filt not available")
+    meta = _kernel_metadata(tmp_path)
+    names = [n for n in meta if "stage1_kernel16" in n]
+    assert names, "stage-1 kernels not found in the library"
+    checked = 0
+    for n in names:
+        dem = subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip()
+        m = re.search(r"stage1_kernel16<(\d), (true|false)>", dem)
+        assert m, dem
+        if m.group(2) == "false" and m.group(1) in ("0", "1"):       # float input, counted waits
+            assert meta[n]["vgpr_spill_count"] == 0 and meta[n]["private_segment_fixed_size"] == 0, (dem, meta[n])
+            checked += 1
+    assert checked == 2
