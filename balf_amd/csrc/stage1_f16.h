@@ -177,6 +177,9 @@ __device__ __forceinline__ const T *uniform_ptr(const T *p) {
 #ifndef BALF_S1_FUSE
 #define BALF_S1_FUSE 1       // 1: the block kernel stores x1 and the channel sums of the RCAB's hidden layer only; tail kernel (MODE 2)
 #endif
+#ifndef BALF_S1_KEEP_X0
+#define BALF_S1_KEEP_X0 1    // block kernel: keep x0 in registers (32; there is room since conv0 left the f16 path) instead of recomputing it: -5 %
+#endif
 #ifndef BALF_S1_STRICT
 #define BALF_S1_STRICT 0     // 1: every hand-placed wait drains the queue (debugging aid)
 #endif
@@ -460,7 +463,11 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             const long opix = ((long)g.n * (H / 2) + (g.y >> 1)) * (W / 2) + (g.x0 >> 1) + sel;
             store_frag_px(A.out, opix, C, 0, q, split8(o0, o1));
         } else {
-        {
+        f4 x0k[(MODE == 1 && BALF_S1_KEEP_X0) ? 2 : 1][(MODE == 1 && BALF_S1_KEEP_X0) ? P : 1];   // (block) x0, kept for x1 = . + x0
+        if constexpr (MODE == 1 && BALF_S1_KEEP_X0) {
+            conv0(x0k);
+            s1_ln_split(x0k, b);
+        } else {
             f4 x0v[2][P];
             conv0(x0v);
             s1_ln_split(x0v, b);
@@ -563,8 +570,12 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             s1_linear(x1, wl + kS1Q2, 2 * 2048, ub);             // K-step 0 = u' half
             STAMP(9);   // RSHMAG dense2 over cat[u', v'] (u' from HBM)
             {
+#if BALF_S1_KEEP_X0
+                f4 (&x0v)[2][P] = x0k;
+#else
                 f4 x0v[2][P];
-                conv0(x0v);                                      // recomputed (24 MFMAs) instead of kept (32 registers)
+                conv0(x0v);                                      // recomputed (8 MFMAs + relu) instead of kept (32 registers)
+#endif
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll

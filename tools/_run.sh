@@ -1,3 +1,2 @@
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python tools/soak.py 30 16 1088 1920 2>&1 | tail -1
-python tools/soak.py 60 3 704 1216 2>&1 | tail -1
+BALF_HIP_LIB=$PWD/balf_amd/libbalf_hip_keepx0.so python tools/check_f16.py 2>&1 | grep -v amdgpu.ids | tail -1
+bash tools/run_variants.sh gpurun_out/csv2 fp16 keepx0 2>&1 | cut -c1-200
