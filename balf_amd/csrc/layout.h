@@ -19,6 +19,10 @@ constexpr int kHeadN = 65;        // 64 cell positions + dustbin
 constexpr int kHeadNPad = 80;     // padded to a multiple of 16 output rows
 constexpr float kLnEps = 1e-5f;
 constexpr float kBnEps = 1e-5f;
+// GELU table of the stage-1 split-f16 kernels (stage1_f16.h): kGeluLutN intervals over [-kGeluLutL, kGeluLutL), one
+// (a, b) pair per interval with gelu(x) ~ a + b x, plus the two exact asymptotes (entry 0: 0, entry N: x)
+constexpr int kGeluLutN = 3072;
+constexpr float kGeluLutL = 6.0f;
 
 struct BranchOff {                // GridGmlpLayer / BlockGmlpLayer
     int ln_g, ln_b;               // .norm
@@ -48,6 +52,7 @@ struct Layout {
     int head_b;                   // [80] dense bias
     int head_alpha, head_beta;    // [80] BatchNorm(eval) as z = lin * alpha + beta
     int u8_lut;                   // [256] float32(i / 255.0): uint8 image -> network input (demo_match.py:22)
+    int gelu_lut;                 // [kGeluLutN + 1][2] chord table of the exact GELU (see kGeluLutN)
     int total;                    // floats
 };
 
@@ -85,6 +90,7 @@ constexpr Layout make_layout() {
     L.head_alpha = take(kHeadNPad);
     L.head_beta = take(kHeadNPad);
     L.u8_lut = take(256);
+    L.gelu_lut = take(2 * (kGeluLutN + 1));
     L.total = o;
     return L;
 }

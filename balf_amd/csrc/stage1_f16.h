@@ -31,8 +31,16 @@ constexpr int kS1BtBytes = 2 * kS1BtPlane;                     // 8192 B per wav
 // byte offset of tokens 4 li .. 4 li + 3 of channel row c (writer) / of tokens 8 j .. 8 j + 7 of row c (reader)
 __device__ __forceinline__ int s1_bt_wr(int c, int li) { return c * 128 + (((li >> 1) ^ (c & 7)) << 4) + (li & 1) * 8; }
 __device__ __forceinline__ int s1_bt_rd(int c, int j) { return c * 128 + ((j ^ (c & 7)) << 4); }
-// LDS image: weight tiles (2 KiB each: [hi 64 x 16 B][lo 64 x 16 B]) ...
-constexpr int kS1Conv0 = 0;                                    // 2 row tiles (built in the kernel from the plain [32,3] matrix)
+// LDS image: the GELU chord table at offset 0 (its byte offsets come straight out of a bit mask, see gelu_lut1), then
+// weight tiles (2 KiB each: [hi 64 x 16 B][lo 64 x 16 B]) ...
+#ifndef BALF_GELU_LUT
+#define BALF_GELU_LUT 1      // 1: GELU of the stage-1 kernels from the LDS chord table (3 vector instructions + 1 LDS read); 0: 2^P form (8)
+#endif
+#ifndef BALF_S1_GELU_CHUNK0
+#define BALF_S1_GELU_CHUNK0 8
+#endif
+constexpr int kS1LutBytes = BALF_GELU_LUT ? ((kGeluLutN + 1) * 8 + 15) / 16 * 16 : 0;
+constexpr int kS1Conv0 = kS1LutBytes;                          // 2 row tiles (built in the kernel from the plain [32,3] matrix)
 constexpr int kS1Q1 = kS1Conv0 + 2 * 2048;                     // 2 row tiles (this branch's half of RSHMAG.dense1)
 constexpr int kS1D1 = kS1Q1 + 2 * 2048;                        // 4 row tiles
 constexpr int kS1Mix = kS1D1 + 4 * 2048;                       // 4 token tiles x 2 K-steps, columns re-ordered
@@ -40,13 +48,13 @@ constexpr int kS1D2 = kS1Mix + 8 * 2048;                       // 2 row tiles
 constexpr int kS1Q2 = kS1D2 + 2 * 2048;                        // block only: 2 row tiles x 2 K-steps
 constexpr int kS1R1 = kS1Q2 + 4 * 2048;
 constexpr int kS1R2 = kS1R1 + 2 * 2048;
-template <int MODE> constexpr int s1_weight_bytes() { return MODE == 0 ? kS1Q2 : kS1R2 + 2 * 2048; }   // MODE 2 (tail): the block image
+template <int MODE> constexpr int s1_weight_bytes() { return MODE == 0 ? kS1Q2 : kS1R2 + 2 * 2048; }   // MODE 2 (tail): the block image (table region unused)
 // ... then per-channel parameters (floats) ...
 enum S1Par { kS1pConv0B = 0, kS1pQ1B = 32, kS1pD1B = 64, kS1pGlnG = 128, kS1pGlnB = 160, kS1pMixB1 = 192, kS1pD2B = 256,
              kS1pQ2B = 288, kS1pR1B = 320, kS1pR2B = 352, kS1pLut = 384, kS1ParFloats = 640 };
 // ... then one transposed token tile per wave.
 #ifndef BALF_S1_NW0
-#define BALF_S1_NW0 12
+#define BALF_S1_NW0 8        // (12 = three waves per SIMD was best with the 2^P GELU; with the table reads in flight it spills at 168 registers)
 #endif
 #ifndef BALF_S1_NW1
 #define BALF_S1_NW1 8
@@ -54,7 +62,7 @@ enum S1Par { kS1pConv0B = 0, kS1pQ1B = 32, kS1pD1B = 64, kS1pGlnG = 128, kS1pGln
 #ifndef BALF_S1_NW2
 #define BALF_S1_NW2 12
 #endif
-template <int MODE> constexpr int s1_waves() { return MODE == 0 ? BALF_S1_NW0 : MODE == 1 ? BALF_S1_NW1 : BALF_S1_NW2; }   // 3 / 2 / 3 waves per SIMD
+template <int MODE> constexpr int s1_waves() { return MODE == 0 ? BALF_S1_NW0 : MODE == 1 ? BALF_S1_NW1 : BALF_S1_NW2; }   // 2 / 2 / 3 waves per SIMD
 template <int MODE> constexpr int s1_lds_bytes() {
     return s1_weight_bytes<MODE>() + kS1ParFloats * 4 + (MODE == 2 ? 0 : s1_waves<MODE>() * kS1BtBytes);   // (no token mix in the tail)
 }
@@ -157,6 +165,73 @@ __device__ __forceinline__ void s1_bias(f4 (&t)[NT][P], const float *par, int q)
     }
 }
 
+// GELU from the chord table in LDS (layout.h: kGeluLutN intervals over [-L, L), weights.hip builds it):
+//   y = clamp01(x / 2L + 1/2)            v_fma_f32 ... clamp  (saturates to the two asymptote entries outside [-L, L))
+//   t = y * 8N + 1.5 * 2^23              the rounded 8 N y lands in the low mantissa bits
+//   (a, b) = table[bits(t) & 0x7FF8]     byte offset of interval floor(round(8 N y) / 8): one ds_read_b64
+//   gelu = a + b x
+// 3 vector instructions (9.4 issue cycles at the measured class rates) + 1 LDS read against 8 (33 cycles) for the 2^P
+// form; the LDS pipe of these kernels was idle three quarters of the time.  Chord error 7.6e-7 (the 2^P form: 6.4e-7).
+__device__ __forceinline__ unsigned gelu_lut_off(float x, float magic) {
+    static_assert((kGeluLutN + 1) * 8 <= 0x8000, "the byte offset mask below is 15 bits");
+    // (x is an MFMA result: the instruction that reads it must be the compiler's -- hipcc pads the MFMA -> VALU read
+    // hazard for its own instructions only, an inline-asm v_fma placed right behind the MFMA read stale registers;
+    // fmed3(., 0, 1) folds into the fma's clamp modifier)
+    const float y = __builtin_amdgcn_fmed3f(fmaf(x, 0.5f / kGeluLutL, 0.5f), 0.0f, 1.0f);
+    const float t = fmaf(y, 8.0f * kGeluLutN, magic);
+    return __builtin_bit_cast(unsigned, t) & 0x7FF8u;
+}
+
+// Eight (or four) values per step: the table reads are issued back to back and waited for inside ONE asm statement (the
+// dynamic LDS block of these kernels starts at LDS address 0 -- they have no static __shared__ --, so the masked bits
+// ARE the address).  Left to itself hipcc waits for every read right behind its issue, spends a v_add_u32 per read on
+// adding the LDS symbol's zero, pairs the final fmas into v_pk_fma_f32 behind three v_mov_b32 each, or (as v_fmac_f32)
+// leaves each result in one half of a 64-bit pair, which fragments the register file into spills.
+template <int N>
+__device__ __forceinline__ void gelu_lut_n(float (&x)[N], float magic) {
+    static_assert(N == 4 || N == 8, "");
+    unsigned o[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = gelu_lut_off(x[i], magic);
+    f2 ab[N];
+    if constexpr (N == 8)
+        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                     "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(ab[0]), "=&v"(ab[1]), "=&v"(ab[2]), "=&v"(ab[3]), "=&v"(ab[4]), "=&v"(ab[5]), "=&v"(ab[6]), "=&v"(ab[7])
+                     : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]));
+    else
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(ab[0]), "=&v"(ab[1]), "=&v"(ab[2]), "=&v"(ab[3])
+                     : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+#pragma unroll
+    for (int i = 0; i < N; ++i)      // (asm: the result goes into x's register)
+        asm("v_fma_f32 %0, %1, %0, %2" : "+v"(x[i]) : "v"(ab[i][1]), "v"(ab[i][0]));
+}
+
+template <int CHUNK, int NT, int P>
+__device__ __forceinline__ void s1_gelu(f4 (&t)[NT][P]) {
+#if BALF_GELU_LUT
+    if (BALF_ABLATE_GELU) return;
+    float magic = 12582912.0f;                   // 1.5 * 2^23, kept in a vector register (the fma's other two operands use the constant bus)
+    asm("" : "+v"(magic));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < P; p += CHUNK / 4) {
+            float v[CHUNK];
+#pragma unroll
+            for (int i = 0; i < CHUNK; ++i) v[i] = t[nt][p + (i >> 2)][i & 3];
+            gelu_lut_n(v, magic);
+#pragma unroll
+            for (int i = 0; i < CHUNK; ++i) t[nt][p + (i >> 2)][i & 3] = v[i];
+        }
+#else
+    gelu<false>(t);
+#endif
+}
+
 // Vector-memory discipline of the float-input kernels (U8 = false).  vmcnt counts loads and stores together, in issue
 // order, and the compiler drains it to zero at the loop's back edge as soon as it has a load of its own pending -- which
 // makes every group wait for the previous group's 8-16 KiB of stores (measured: 40 % of the grid kernel's time).  So every
@@ -195,6 +270,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     constexpr int C = kS1C, P = 4, NW = s1_waves<MODE>(), NTHR = NW * 64;
     constexpr int BM = MODE == 0 ? 0 : 1;                        // branch whose weights / token geometry this kernel uses
     constexpr bool TAIL = MODE == 2;                             // the stage's tail (see the loop body)
+    constexpr int kGeluChunk = MODE == 0 ? BALF_S1_GELU_CHUNK0 : 8; (void)kGeluChunk;   // table reads in flight per wave (registers: 3 per value)
     constexpr int STAMP_KID = BM; (void)STAMP_KID;
     STAMP_DECL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -212,6 +288,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             for (int i = threadIdx.x * 16; i < bytes; i += NTHR * 16)
                 *reinterpret_cast<uint4 *>(smem_raw + dst + i) = *reinterpret_cast<const uint4 *>(s + i);
         };
+        if (BALF_GELU_LUT && !TAIL) copy(0, kLayout.gelu_lut, kS1LutBytes);
         copy(kS1Q1, S.q1_w + BM * (2 * 512), 2 * 2048);        // rows BM*C .. : tiles 2*BM, 2*BM+1 (512 floats each)
         copy(kS1D1, Br.d1_w, 4 * 2048);
         copy(kS1D2, Br.d2_w, 2 * 2048);
@@ -476,7 +553,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         f4 z[2][P];                                              // u (grid) / v (block): kept for the branch residual
         s1_bias(z, par + kS1pQ1B, q);
         s1_linear(z, wl + kS1Q1, 2048, b);
-        gelu<false>(z);
+        s1_gelu<kGeluChunk>(z);
         STAMP(3);   // dense1 half + GELU
         s1_ln_split(z, b);
         STAMP(4);   // LN + split
@@ -484,13 +561,13 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         f4 ga[2][P];
         s1_bias(ga, par + kS1pD1B, q);
         s1_linear(ga, wl + kS1D1, 2048, b);
-        gelu<false>(ga);
+        s1_gelu<kGeluChunk>(ga);
         STAMP(5);   // branch dense1 (a half) + GELU
         {
             f4 gb[2][P];
             s1_bias(gb, par + kS1pD1B + C, q);
             s1_linear(gb, wl + kS1D1 + 2 * 2048, 2048, b);
-            gelu<false>(gb);
+            s1_gelu<kGeluChunk>(gb);
             // gating LayerNorm (affine) -> transposed token tile bT[hi|lo][c][t], t = 4 li + p: 8-byte stores
             float rstd[P], shift[P];
 #pragma unroll

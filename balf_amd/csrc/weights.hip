@@ -216,5 +216,25 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
         blob[kLayout.head_beta + c] = (float)((double)h[3][c] - (double)h[4][c] * alpha);
     }
     for (int i = 0; i < 256; ++i) blob[kLayout.u8_lut + i] = (float)((double)i / 255.0);
+    // GELU chord table (nn.GELU() default = erf form, mlp_ma_decoder.py:52,99,126).  The kernels' index arithmetic
+    // (stage1_f16.h: gelu_lut1) puts x in interval i when N (x + L) / 2L lies in [i - 1/16, i + 15/16); each chord is
+    // shifted by half its largest deviation (equi-oscillating).  Entry 0 (x < -L + 15h/16) is exactly 0 and entry N
+    // (x >= L - h/16) exactly x: |gelu - asymptote| < 7e-9 out there.
+    {
+        auto g = [](double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752440)); };
+        const double L = (double)kGeluLutL, hh = 2.0 * L / kGeluLutN;
+        float *lut = blob + kLayout.gelu_lut;
+        for (int i = 0; i <= kGeluLutN; ++i) {
+            double a = 0.0, b = (i == kGeluLutN) ? 1.0 : 0.0;
+            if (i > 0 && i < kGeluLutN) {
+                const double x0 = -L + (i - 1.0 / 16.0) * hh, x1 = x0 + hh, xm = 0.5 * (x0 + x1);
+                b = (g(x1) - g(x0)) / (x1 - x0);
+                a = g(x0) - b * x0;
+                a += 0.5 * (g(xm) - (a + b * xm));
+            }
+            lut[2 * i] = (float)a;
+            lut[2 * i + 1] = (float)b;
+        }
+    }
     return BALF_OK;
 }
