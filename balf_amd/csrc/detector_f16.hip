@@ -1663,7 +1663,8 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
         auto c0k = stage_cs_kernel16<C, CIN, 0>;
         auto c1k = stage_cs_kernel16<C, CIN, 1>;
         constexpr int G = cs_groups<C>();
-        constexpr int clds = cs_lds_bytes<C>() * G;
+        constexpr int clds0 = cs_lds_bytes<C>() * G + cs_lut_bytes<0>(), clds1 = cs_lds_bytes<C>() * G + cs_lut_bytes<1>();
+        constexpr int clds = clds0 > clds1 ? clds0 : clds1;
         static_assert(clds <= 160 * 1024, "channel-split LDS image");
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(c0k), hipFuncAttributeMaxDynamicSharedMemorySize, clds) !=
                 hipSuccess ||
@@ -1673,8 +1674,8 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
         per_img = (H / 8) * (W / 8);                       // one partial-sum row per token group
         const unsigned groups = (unsigned)((long)B * per_img);
         if (groups % G != 0) return BALF_ERR_ARG;              // (H, W multiples of 64: per_img is a multiple of 4 at C <= 128)
-        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(c0k, dim3(groups / G), dim3(cs_waves<C>() * G * 64), clds, st, a));
-        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(c1k, dim3(groups / G), dim3(cs_waves<C>() * G * 64), clds, st, a));
+        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(c0k, dim3(groups / G), dim3(cs_waves<C>() * G * 64), clds0, st, a));
+        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(c1k, dim3(groups / G), dim3(cs_waves<C>() * G * 64), clds1, st, a));
     } else if constexpr ((C == 256 && BALF_NS256 != 0) || (C == 128 && BALF_NS128 != 0) || (C == 64 && BALF_NS64 != 0)) {
         constexpr int nlds = ns_lds_bytes<C>();
         static_assert(nlds <= (C >= 256 ? 160 : 80) * 1024, "N-split LDS image");

@@ -23,6 +23,12 @@ constexpr float kBnEps = 1e-5f;
 // (a, b) pair per interval with gelu(x) ~ a + b x, plus the two exact asymptotes (entry 0: 0, entry N: x)
 constexpr int kGeluLutN = 3072;
 constexpr float kGeluLutL = 6.0f;
+// GELU table of the channel-split kernels (stage_cs_f16.h), which have 6 KB of LDS to spare, not 24: gelu(x) = x / 2 +
+// E(|x|), E(a) = a erf(a / sqrt 2) / 2, chords of E over intervals whose width doubles where the curvature allows it:
+// kGeluLogM intervals each over |x| in [0, 1), [1, 3), [3, 7) -- the binades of (|x| + 1) / 8, so the interval index is
+// a bit field of that float -- plus the asymptote entry E = |x| / 2 for |x| >= 7.  Same chord error as the table above.
+constexpr int kGeluLogM = 256;
+constexpr int kGeluLogEntries = 3 * kGeluLogM + 1;
 
 struct BranchOff {                // GridGmlpLayer / BlockGmlpLayer
     int ln_g, ln_b;               // .norm
@@ -53,6 +59,7 @@ struct Layout {
     int head_alpha, head_beta;    // [80] BatchNorm(eval) as z = lin * alpha + beta
     int u8_lut;                   // [256] float32(i / 255.0): uint8 image -> network input (demo_match.py:22)
     int gelu_lut;                 // [kGeluLutN + 1][2] chord table of the exact GELU (see kGeluLutN)
+    int gelu_log;                 // [kGeluLogEntries][2] chord table of E(|x|) (see kGeluLogM)
     int total;                    // floats
 };
 
@@ -91,6 +98,7 @@ constexpr Layout make_layout() {
     L.head_beta = take(kHeadNPad);
     L.u8_lut = take(256);
     L.gelu_lut = take(2 * (kGeluLutN + 1));
+    L.gelu_log = take(2 * kGeluLogEntries);
     L.total = o;
     return L;
 }

@@ -41,6 +41,73 @@ template <int C> constexpr int cs_tail_lds_bytes() {      // tail: B fragments, 
 template <int C> constexpr int cs_lds_bytes() {
     return cs_bx_bytes<C>() + cs_bt_bytes<C>() + (cs_mix_in_lds<C>() ? 8 * 2048 : 0) + cs_waves<C>() * 4 * 16 * 8;
 }
+#ifndef BALF_CS_GELU_CHUNK
+#define BALF_CS_GELU_CHUNK 8 // table reads in flight per wave (3 registers per value)
+#endif
+#ifndef BALF_CS_GELU_LUT
+#define BALF_CS_GELU_LUT 1   // bit m set: GELU of the MODE-m kernels from the log-spaced chord table (layout.h: kGeluLogM) at LDS offset 0; else 2^P form
+#endif
+// Measured per 8 x 1088x1920, same box: grid kernels C = 64 1.13 -> 1.05 ms, C = 256 0.56 -> 0.54, C = 128 unchanged; the block
+// kernels (11-13 barriers per group: every exposed LDS round trip of a table chunk is on the group's critical path) lose
+// at C = 64 (1.37 -> 1.45) and gain nothing above, so they keep the 2^P form.
+template <int MODE> constexpr bool cs_gelu_lut() { return MODE < 2 && ((BALF_CS_GELU_LUT >> MODE) & 1) != 0; }
+template <int MODE> constexpr int cs_lut_bytes() { return cs_gelu_lut<MODE>() ? (kGeluLogEntries * 8 + 15) / 16 * 16 : 0; }
+
+// GELU from the log-spaced table: gelu(x) = x / 2 + E(|x|), E from the chord of the interval that the float
+// s = clamp01((|x| + 1) / 8) names with its low two exponent bits and top eight mantissa bits:
+//   s          v_fma_f32 |x|, 1/8, 1/8 clamp     (the compiler's instruction: x is an MFMA result, see stage1_f16.h)
+//   off        (bits(s) >> 12) & 0x1FF8          byte offset of the (A, B) pair; s = 1 (|x| >= 7) names the asymptote entry
+//   gelu       fma(0.5, x, fma(B, |x|, A))
+// 5 vector instructions (17 issue cycles at the measured class rates) + 1 LDS read against 8 (33) for the 2^P form.
+template <int N>
+__device__ __forceinline__ void gelu_log_n(float (&x)[N]) {
+    static_assert(N == 4 || N == 8, "");
+    static_assert(kGeluLogM == 256, "the bit field below is 2 exponent + 8 mantissa bits");
+    unsigned o[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float s = __builtin_amdgcn_fmed3f(fmaf(__builtin_fabsf(x[i]), 0.125f, 0.125f), 0.0f, 1.0f);
+        o[i] = (__builtin_bit_cast(unsigned, s) >> 12) & 0x1FF8u;
+    }
+    f2 ab[N];
+    // (the dynamic LDS block starts at LDS address 0 and the table is its first region: the offset IS the address)
+    if constexpr (N == 8)
+        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                     "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(ab[0]), "=&v"(ab[1]), "=&v"(ab[2]), "=&v"(ab[3]), "=&v"(ab[4]), "=&v"(ab[5]), "=&v"(ab[6]), "=&v"(ab[7])
+                     : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]));
+    else
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(ab[0]), "=&v"(ab[1]), "=&v"(ab[2]), "=&v"(ab[3])
+                     : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float e;
+        asm("v_fma_f32 %1, %2, |%0|, %3\n\tv_fma_f32 %0, 0.5, %0, %1" : "+v"(x[i]), "=&v"(e) : "v"(ab[i][1]), "v"(ab[i][0]));
+    }
+}
+
+template <bool LUT, int CHUNK>
+__device__ __forceinline__ void cs_gelu(f4 (&t)[2][4]) {
+    if constexpr (!LUT) {
+        gelu<false>(t);
+        return;
+    }
+    if (BALF_ABLATE_GELU) return;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int p = 0; p < 4; p += CHUNK / 4) {
+            float v[CHUNK];
+#pragma unroll
+            for (int i = 0; i < CHUNK; ++i) v[i] = t[nt][p + (i >> 2)][i & 3];
+            gelu_log_n(v);
+#pragma unroll
+            for (int i = 0; i < CHUNK; ++i) t[nt][p + (i >> 2)][i & 3] = v[i];
+        }
+}
 
 #ifndef BALF_CS_SCHED
 #define BALF_CS_SCHED 1      // 1: a scheduling fence only behind the weight requests (measured best; 0: none, 2: also behind the MFMAs)
@@ -189,7 +256,7 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
     // (G = 2) two token groups per workgroup, each with its own LDS image and its own waves; they share the barriers only
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = (G == 1) ? 0 : wave_all / NW;
-    unsigned char *smem_raw = smem_all + grp * (MODE == 2 ? cs_tail_lds_bytes<C>() : cs_lds_bytes<C>());
+    unsigned char *smem_raw = smem_all + (MODE == 2 ? grp * cs_tail_lds_bytes<C>() : cs_lut_bytes<MODE>() + grp * cs_lds_bytes<C>());
     h8 *bx = reinterpret_cast<h8 *>(smem_raw);                                            // shared B fragments
     unsigned char *btr = smem_raw + cs_bx_bytes<C>();                                      // token tiles, later u'
     h8 *bu = reinterpret_cast<h8 *>(btr);
@@ -205,6 +272,7 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
     const StageOff &S = A.off;
     const BranchOff &Br = S.br[MODE == 0 ? 0 : 1];
     constexpr bool TAIL = MODE == 2;
+    constexpr int kGeluChunk = BALF_CS_GELU_CHUNK; (void)kGeluChunk;
     const char *bb = reinterpret_cast<const char *>(blob);
     const CsBlob bl{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(blob), 0, 0x7fffffff, 0x27000), (unsigned)lane * 16u};
     const CsBlob bq{bl.rsrc, (unsigned)q * 16u};                                           // per-channel vectors: channels 4 q .. 4 q + 3
@@ -246,6 +314,10 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
         for (int f = 0; f < 2; ++f) {
             const int fi = 2 * wave + f, kk = fi >> 2, p = fi & 3;
             xin[f] = load_frag_px(A.X, pix0 + p * pstep, CIN, kk, q);
+        }
+        if constexpr (cs_gelu_lut<MODE>()) {     // GELU chord table -> LDS offset 0 (published by the barrier below)
+            for (int i = threadIdx.x; i < cs_lut_bytes<MODE>() / 16; i += NW * G * 64)
+                *reinterpret_cast<uint4 *>(smem_all + i * 16) = *reinterpret_cast<const uint4 *>(bb + (size_t)kLayout.gelu_log * 4 + i * 16);
         }
         if constexpr (cs_mix_in_lds<C>()) {
             static_assert(!cs_mix_in_lds<C>() || G == 1, "the LDS copy of the mixing matrix is per workgroup");
@@ -432,7 +504,7 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
     STAMPV(4);   // dense1 half
     cs_wload(wn, bl, w_d1a, KS, 0);
     bn = bias_load(Br.d1_b);
-    gelu<false>(z);
+    cs_gelu<cs_gelu_lut<MODE>(), kGeluChunk>(z);
     ln_publish(z);
     STAMPV(5);   // GELU, LN exchange, publish
     // ---- branch dense1: a half, b half (same B operand) ----
@@ -442,7 +514,7 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
     STAMPV(6);   // branch dense1, a half
     cs_wload(wn, bl, w_d1b, KS, 0);
     bn = bias_load(Br.d1_b + C);
-    gelu<false>(ga);
+    cs_gelu<cs_gelu_lut<MODE>(), kGeluChunk>(ga);
     {
         f4 gb[2][4];
         bias_fill(gb, bn);
@@ -450,7 +522,7 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
         STAMPV(7);   // GELU(a), b half
         cs_wload(wn, bl, w_d2, KS, 0);                             // dense2's first fragments travel through the token mix
         bn = bias_load(Br.d2_b);
-        gelu<false>(gb);
+        cs_gelu<cs_gelu_lut<MODE>(), kGeluChunk>(gb);
         float rstd[P], shift[P];
         ln_stats_all(gb, rstd, shift);                         // gating LayerNorm (affine) over all C channels
 #pragma unroll

@@ -235,6 +235,21 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
             lut[2 * i] = (float)a;
             lut[2 * i + 1] = (float)b;
         }
+        // E(a) = a erf(a / sqrt 2) / 2 over a = |x|: entry k * M + j covers a in [2^k (1 + j / M) - 1, + 2^k / M)
+        auto E = [](double a) { return 0.5 * a * erf(a * 0.70710678118654752440); };
+        float *lg = blob + kLayout.gelu_log;
+        for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < kGeluLogM; ++j) {
+                const double w = (double)(1 << k) / kGeluLogM, a0 = (double)(1 << k) * (1.0 + (double)j / kGeluLogM) - 1.0;
+                const double a1 = a0 + w, am = 0.5 * (a0 + a1);
+                const double b = (E(a1) - E(a0)) / w;
+                double a = E(a0) - b * a0;
+                a += 0.5 * (E(am) - (a + b * am));
+                lg[2 * (k * kGeluLogM + j)] = (float)a;
+                lg[2 * (k * kGeluLogM + j) + 1] = (float)b;
+            }
+        lg[2 * 3 * kGeluLogM] = 0.0f;                    // |x| >= 7: E = |x| / 2 (to 1e-11)
+        lg[2 * 3 * kGeluLogM + 1] = 0.5f;
     }
     return BALF_OK;
 }
