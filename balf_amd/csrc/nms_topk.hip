@@ -18,6 +18,8 @@
 //                          survivors reach it, a second radix select on the flat index keeps the
 //                          raster-first K of them (as the reference does); LDS bitonic sort of the
 //                          <= K selected (score desc, index asc) and the padded output rows.
+#include <cstdint>
+#include <cstdlib>
 #include "common.h"
 #include "prof.h"
 
@@ -174,6 +176,154 @@ __global__ __launch_bounds__(NTHREADS) void nms_tile_kernel(NmsArgs a) {
             const int gy = ty0 + seg * SEG + j;
             a.surv[pos++] = make_int2(gy * a.W + gx, __float_as_int(cen[j]));
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Window 15, survivor-list mode, 16-byte aligned rows: the tuned form of nms_tile_kernel<15>.
+//   * one 64 (wide) x 114 (tall) output tile per workgroup: 128 input rows, so the row pass is exactly two items per
+//     thread (the 64 x 64 tile has 78 rows x 4 segments = 312 items for 256 threads: a second round at 22 % use) and
+//     the vertical halo is 12 % instead of 22 %; the kernel's time goes with the number of workgroups (per-tile overheads);
+//   * the tile + halo (columns tx0 - 8 .. tx0 + 71) comes in as 16-byte loads, five per thread, goes to LDS as
+//     16-byte stores and is read back by the row pass as 16-byte reads (pitch 21 x 16 B: consecutive rows fall into
+//     different bank groups); the per-element crop / border / clip rules are applied in registers;
+//   * the maxima are integer maxima on the float bits, three inputs per instruction (v_max3_i32), windows
+//     3 -> 9 -> 15: 66 instructions per 16 outputs instead of 95 two-input v_max_f32 (which cost 5.8 cycles each).
+//     Every value here is a score (>= 0 counts; anything <= 0 never survives) or the clip value -inf, and signed
+//     integer order equals float order on positive floats, so whenever the centre can survive (> 0) the integer
+//     window maximum IS the float window maximum.  (The dense apply_nms map needs the maximum of negative windows
+//     too: it stays with nms_tile_kernel.)
+// Same survivors as nms_tile_kernel<15>; their order in the list is arbitrary in both (selection is by value).
+// ---------------------------------------------------------------------------------------------
+constexpr int V_INH = 128, V_TH = V_INH - 14, V_IN4 = 20, V_PIN4 = 21, V_PROW4 = 17, V_SEGC = (V_TH + 3) / 4, V_NLD = V_INH * V_IN4 / NTHREADS;
+static_assert(V_INH * V_IN4 % NTHREADS == 0 && V_INH % 64 == 0, "whole chunks per thread, whole waves per row-pass round");
+
+__device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }   // v_max3_i32
+
+// o[i] = max(v[i .. i + 14]), i < N, on the float bits
+template <int N>
+__device__ __forceinline__ void window15_i(const int (&v)[N + 14], int (&o)[N]) {
+    int t3[N + 12], t9[N + 6];
+#pragma unroll
+    for (int i = 0; i < N + 12; ++i) t3[i] = imax3(v[i], v[i + 1], v[i + 2]);
+#pragma unroll
+    for (int i = 0; i < N + 6; ++i) t9[i] = imax3(t3[i], t3[i + 3], t3[i + 6]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = max(t9[i], t9[i + 6]);
+}
+
+__global__ __launch_bounds__(NTHREADS) void nms_tile15_vec_kernel(NmsArgs a) {
+    __shared__ int4 s_in[V_INH * V_PIN4];
+    __shared__ int4 s_row[V_INH * V_PROW4];
+    __shared__ int s_scan[4];
+    __shared__ int s_base;
+    const int b = blockIdx.z;
+    const int ty0 = blockIdx.y * V_TH, tx0 = blockIdx.x * TW;
+    const float *img = a.src + (long)b * a.Hs * a.Ws;
+    const int tid = threadIdx.x;
+    constexpr int NEG_INF = (int)0xFF800000u;
+
+    {   // tile + halo -> LDS: 64 rows x 20 chunks of four columns = 5 chunks per thread, all requested before the first store
+        // (block-uniform) the tile and its halo lie inside the border frame -- 85 % of the tiles of a 1080p map: plain copy
+        const bool interior = tx0 - 8 >= a.border && tx0 + 72 <= a.W - a.border && ty0 - 7 >= a.border && ty0 - 7 + V_INH <= a.H - a.border;
+        int4 tmp[V_NLD];
+        if (interior) {
+            const float *base = img + (long)(a.crop_y + ty0 - 7) * a.Ws + (a.crop_x + tx0 - 8);
+#pragma unroll
+            for (int j = 0; j < V_NLD; ++j) {
+                const int i = tid + j * NTHREADS;
+                const int r = i / V_IN4, c4 = i - r * V_IN4;
+                tmp[j] = *reinterpret_cast<const int4 *>(base + (long)r * a.Ws + 4 * c4);
+            }
+        } else {
+            // every chunk is loaded from a clamped (always valid) address -- no branch around the loads, they all go out
+            // together --; an address is only ever clamped for chunks whose four elements are all clipped (x, crop_x and
+            // the pitch are multiples of four: a chunk never straddles the end of a source row)
+            int xs[V_NLD], ys[V_NLD];
+#pragma unroll
+            for (int j = 0; j < V_NLD; ++j) {
+                const int i = tid + j * NTHREADS;
+                const int r = i / V_IN4, c4 = i - r * V_IN4;
+                ys[j] = ty0 - 7 + r;
+                xs[j] = tx0 - 8 + 4 * c4;
+                const int yc = min(max(ys[j], 0), a.H - 1), sx = min(max(a.crop_x + xs[j], 0), a.Ws - 4);
+                tmp[j] = *reinterpret_cast<const int4 *>(img + (long)(a.crop_y + yc) * a.Ws + sx);
+            }
+#pragma unroll
+            for (int j = 0; j < V_NLD; ++j) {
+                const int y = ys[j], x = xs[j];
+                const bool row_out = y < 0 || y >= a.H, row_border = y < a.border || y >= a.H - a.border;
+                int e[4] = {tmp[j].x, tmp[j].y, tmp[j].z, tmp[j].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int xx = x + k;
+                    const bool out = row_out || xx < 0 || xx >= a.W;                                  // clipped window
+                    const bool bord = row_border || xx < a.border || xx >= a.W - a.border;            // remove_borders
+                    e[k] = out ? NEG_INF : (bord ? 0 : e[k]);
+                }
+                tmp[j] = make_int4(e[0], e[1], e[2], e[3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V_NLD; ++j) {
+            const int i = tid + j * NTHREADS;
+            const int r = i / V_IN4, c4 = i - r * V_IN4;
+            s_in[r * V_PIN4 + c4] = tmp[j];
+        }
+    }
+    __syncthreads();
+
+    // row pass: lane = input row, wave = 16-column segment; outputs x = 16 seg .. + 15 need tile columns 16 seg + 1 .. + 30
+#pragma unroll
+    for (int rr = 0; rr < V_INH / 64; ++rr) {
+        const int r = rr * 64 + (tid & 63), seg = tid >> 6;
+        int w[32];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int4 q = s_in[r * V_PIN4 + 4 * seg + k];
+            w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+        }
+        int v[30], o[16];
+#pragma unroll
+        for (int k = 0; k < 30; ++k) v[k] = w[k + 1];
+        window15_i<16>(v, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_row[r * V_PROW4 + 4 * seg + k] = make_int4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    }
+    __syncthreads();
+
+    // column pass: thread = (column, quarter); a quarter owns V_SEGC output rows (the last one starts early so that its
+    // input rows stay inside the tile, and drops the rows the third quarter already owns)
+    const int x = tid & 63, qd = tid >> 6;
+    const int start = qd < 3 ? V_SEGC * qd : V_TH - V_SEGC, first = V_SEGC * qd - start;
+    const int *rowp = reinterpret_cast<const int *>(s_row), *inp = reinterpret_cast<const int *>(s_in);
+    int v[V_SEGC + 14], m[V_SEGC];
+#pragma unroll
+    for (int k = 0; k < V_SEGC + 14; ++k) v[k] = rowp[(start + k) * (4 * V_PROW4) + x];
+    window15_i<V_SEGC>(v, m);
+    const int gx = tx0 + x;
+    unsigned keepmask = 0;
+    int cen[V_SEGC];
+#pragma unroll
+    for (int j = 0; j < V_SEGC; ++j) {
+        const int gy = ty0 + start + j;
+        cen[j] = inp[(start + j + 7) * (4 * V_PIN4) + x + 8];
+        if (j >= first && gy < a.H && gx < a.W && cen[j] == m[j] && cen[j] > 0) keepmask |= 1u << j;   // (> 0 as int == > 0 as float)
+    }
+    int total;
+    const int excl = block_exclusive_scan(__popc(keepmask), s_scan, &total);
+    if (total == 0) return;                                   // block-uniform
+    if (tid == 0) s_base = atomicAdd(&a.surv_count[b], total);
+    __syncthreads();
+    long pos = (long)b * a.cap + s_base + excl;
+    // (a thread keeps 0.1 points on average: a loop over the set bits, not V_SEGC predicated stores)
+    while (keepmask) {
+        const int j = __builtin_ctz(keepmask);
+        keepmask &= keepmask - 1;
+        int c = cen[0];
+#pragma unroll
+        for (int t = 1; t < V_SEGC; ++t) c = (t == j) ? cen[t] : c;
+        a.surv[pos++] = make_int2((ty0 + start + j) * a.W + gx, c);
     }
 }
 
@@ -449,6 +599,15 @@ __global__ __launch_bounds__(SEL_THREADS) void topk_select_kernel(const int2 *su
 int launch_nms_tiles(const NmsArgs &a, int B, hipStream_t stream) {
     dim3 grid(balf_ceil_div(a.W, TW), balf_ceil_div(a.H, TH), B), block(NTHREADS);
     if (balf_prof::g_on) balf_prof::before(balf_prof::kNmsTile, stream);
+    // window 15 into the survivor list with 16-byte aligned rows (every caller of the detection path): the tuned kernel
+    static const bool no_vec = getenv("BALF_NMS_NO_VEC") != nullptr;      // (A/B switch, development aid)
+    if (a.size == 15 && a.dense == nullptr && !no_vec && a.Ws % 4 == 0 && a.crop_x % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 && ((long)a.Hs * a.Ws) % 4 == 0) {
+        hipLaunchKernelGGL(nms_tile15_vec_kernel, dim3(balf_ceil_div(a.W, TW), balf_ceil_div(a.H, V_TH), B), block, 0, stream, a);
+        if (balf_prof::g_on) balf_prof::after(stream);
+        BALF_LAUNCH_CHECK();
+        return BALF_OK;
+    }
     switch (a.size) {
         case 15: hipLaunchKernelGGL(nms_tile_kernel<15>, grid, block, 0, stream, a); break;
         case 5: hipLaunchKernelGGL(nms_tile_kernel<5>, grid, block, 0, stream, a); break;
