@@ -132,3 +132,35 @@ def test_pack_rejects_bad_arguments(lib):
     small = np.zeros(16, np.float32)
     assert lib.balf_pack_weights(ptrs, n, 0, small.ctypes.data, small.nbytes) == -3
     assert lib.balf_pack_weights(ptrs, n - 1, 0, small.ctypes.data, small.nbytes) == -1
+
+
+def test_gelu_chord_tables(lib):
+    """The two GELU tables at the end of the blob (layout.h: kGeluLutN / kGeluLogM), evaluated with the kernels' index
+    arithmetic restated in float32 NumPy (stage1_f16.h: gelu_lut_off, stage_cs_f16.h: gelu_log_n), against the erf form
+    in float64: nn.GELU() of /root/reference/balf/model/mlp_ma_decoder.py:52,99,126."""
+    from scipy.special import erf
+    blob = pack(lib, synth.synthetic_state_dict(5))
+    u8 = (np.arange(256, dtype=np.float64) / 255.0).astype(np.float32)
+    o = next(int(i) for i in np.flatnonzero(blob == u8[1]) if np.array_equal(blob[i - 1:i + 255], u8)) - 1
+    n_uni, m_log = 3072, 256
+    uni = blob[o + 256:o + 256 + 2 * (n_uni + 1)].reshape(-1, 2)
+    o_log = o + 256 + (2 * (n_uni + 1) + 63) // 64 * 64
+    log = blob[o_log:o_log + 2 * (3 * m_log + 1)].reshape(-1, 2)
+    assert o_log + 2 * (3 * m_log + 1) <= blob.size
+    x = np.concatenate([np.linspace(-9, 9, 400001), [0.0, -0.0, 6.0, -6.0, 7.0, -7.0, 5.99999, 30.0, -30.0, 1e-30]]).astype(np.float32)
+    ref = 0.5 * x.astype(np.float64) * (1.0 + erf(x.astype(np.float64) / np.sqrt(2.0)))
+    f32 = np.float32
+    # stage 1: y = clamp01(x / 12 + 1/2); t = y * 8N + 1.5 * 2^23; byte offset = bits(t) & 0x7FF8; gelu = a + b x
+    y = np.clip(x * f32(0.5 / 6.0) + f32(0.5), f32(0), f32(1)).astype(np.float32)
+    t = (y * f32(8.0 * n_uni) + f32(12582912.0)).astype(np.float32)
+    idx = (t.view(np.uint32) & np.uint32(0x7FF8)) >> 3
+    assert idx.max() == n_uni and idx.min() == 0
+    got = uni[idx, 0].astype(np.float32) + uni[idx, 1].astype(np.float32) * x
+    assert np.abs(got - ref).max() < 1.2e-6
+    # stages 2-4 (grid kernels): s = clamp01((|x| + 1) / 8); byte offset = (bits(s) >> 12) & 0x1FF8; gelu = x / 2 + (A + B |x|)
+    s = np.clip(np.abs(x) * f32(0.125) + f32(0.125), f32(0), f32(1)).astype(np.float32)
+    idx = ((s.view(np.uint32) >> 12) & np.uint32(0x1FF8)) >> 3
+    assert idx.max() == 3 * m_log and idx.min() == 0
+    e = log[idx, 1].astype(np.float32) * np.abs(x) + log[idx, 0].astype(np.float32)
+    got = f32(0.5) * x + e.astype(np.float32)
+    assert np.abs(got - ref).max() < 1.2e-6
