@@ -36,8 +36,11 @@ def _kernel_metadata(tmp_path):
         subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}",
                         "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
         notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", str(co)], check=True, capture_output=True, text=True).stdout
-        for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", notes, re.S):
-            meta[m.group(1)] = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|private_segment_fixed_size):\s+(\d+)", m.group(2))}
+        # (the note's keys are sorted: .group_segment_fixed_size precedes .name, the register counts follow it)
+        for m in re.finditer(r"\.group_segment_fixed_size:\s+(\d+)\n((?:(?!\.group_segment_fixed_size).)*?)\.name:\s+(\S+)\n(.*?)\.wavefront_size", notes, re.S):
+            d = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|private_segment_fixed_size):\s+(\d+)", m.group(4))}
+            d["group_segment_fixed_size"] = int(m.group(1))
+            meta[m.group(3)] = d
     return meta
 
 
@@ -56,3 +59,16 @@ def test_asm_load_kernels_do_not_spill(tmp_path):
             assert meta[n]["vgpr_spill_count"] == 0 and meta[n]["private_segment_fixed_size"] == 0, (dem, meta[n])
             checked += 1
     assert checked == 2
+
+
+def test_table_gelu_kernels_have_no_static_lds(tmp_path):
+    """The table-GELU kernels (stage1_f16.h: gelu_lut_n, stage_cs_f16.h: gelu_log_n) use the masked index bits as the LDS
+    ADDRESS of the table entry: the table is the first region of the dynamic LDS block, which starts at LDS address 0 only
+    while the kernel has no static __shared__ allocation (those come first).  Also: none of them may spill -- a spilled
+    address or pair register between the asm blocks would be a scratch access the hand-placed waits do not cover."""
+    meta = _kernel_metadata(tmp_path)
+    names = [n for n in meta if "stage1_kernel16" in n or "stage_cs_kernel16" in n]
+    assert len(names) >= 6 + 8, names
+    for n in names:
+        assert meta[n]["group_segment_fixed_size"] == 0, (n, meta[n])
+        assert meta[n]["vgpr_spill_count"] == 0, (n, meta[n])
