@@ -94,11 +94,11 @@ __device__ __forceinline__ void quarter_allreduce2(float &s, float &ss) {
 template <int NT, int P>
 __device__ __forceinline__ void ln_stats1(const f4 (&x)[NT][P], int p, float &rstd, float &shift) {
     constexpr float inv_c = 1.0f / (16 * NT);
-    float s = 0.0f, ss = 0.0f;
+    float s = x[0][p][0], ss = x[0][p][0] * x[0][p][0];      // (not 0 + x: hipcc keeps that add -- it turns -0 into +0)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = (nt == 0 ? 1 : 0); r < 4; ++r) {
             s += x[nt][p][r];
             ss = fmaf(x[nt][p][r], x[nt][p][r], ss);
         }

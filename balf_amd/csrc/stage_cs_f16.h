@@ -368,11 +368,11 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
             float c[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                float s = 0.0f, ss = 0.0f;
+                float s = x[0][p][0], ss = x[0][p][0] * x[0][p][0];     // (not 0 + x: hipcc keeps that add)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { s += x[nt][p][r]; ss = fmaf(x[nt][p][r], x[nt][p][r], ss); }
+                    for (int r = (nt == 0 ? 1 : 0); r < 4; ++r) { s += x[nt][p][r]; ss = fmaf(x[nt][p][r], x[nt][p][r], ss); }
                 const auto r0 = __builtin_amdgcn_permlane16_swap(u(s), u(ss), false, false);   // rows [s0 ss0 s2 ss2], [s1 ss1 s3 ss3]
                 c[p] = f(r0[0]) + f(r0[1]);                                                    // [S01 SS01 S23 SS23]
             }
