@@ -36,9 +36,6 @@ __device__ __forceinline__ int s1_bt_rd(int c, int j) { return c * 128 + ((j ^ (
 #ifndef BALF_GELU_LUT
 #define BALF_GELU_LUT 1      // 1: GELU of the stage-1 kernels from the LDS chord table (3 vector instructions + 1 LDS read); 0: 2^P form (8)
 #endif
-#ifndef BALF_S1_GELU_CHUNK0
-#define BALF_S1_GELU_CHUNK0 8
-#endif
 constexpr int kS1LutBytes = BALF_GELU_LUT ? ((kGeluLutN + 1) * 8 + 15) / 16 * 16 : 0;
 constexpr int kS1Conv0 = kS1LutBytes;                          // 2 row tiles (built in the kernel from the plain [32,3] matrix)
 constexpr int kS1Q1 = kS1Conv0 + 2 * 2048;                     // 2 row tiles (this branch's half of RSHMAG.dense1)
@@ -182,51 +179,56 @@ __device__ __forceinline__ unsigned gelu_lut_off(float x, float magic) {
     return __builtin_bit_cast(unsigned, t) & 0x7FF8u;
 }
 
-// Eight (or four) values per step: the table reads are issued back to back and waited for inside ONE asm statement (the
-// dynamic LDS block of these kernels starts at LDS address 0 -- they have no static __shared__ --, so the masked bits
-// ARE the address).  Left to itself hipcc waits for every read right behind its issue, spends a v_add_u32 per read on
-// adding the LDS symbol's zero, pairs the final fmas into v_pk_fma_f32 behind three v_mov_b32 each, or (as v_fmac_f32)
-// leaves each result in one half of a 64-bit pair, which fragments the register file into spills.
-template <int N>
-__device__ __forceinline__ void gelu_lut_n(float (&x)[N], float magic) {
-    static_assert(N == 4 || N == 8, "");
-    unsigned o[N];
+// A tensor's 32 values per lane go through the table as a software pipeline in chunks of BALF_S1_GELU_CH: ordinary LDS
+// loads from raw addresses (the dynamic LDS block of these kernels starts at LDS address 0 -- they have no static
+// __shared__ --, so the masked bits ARE the address; hipcc otherwise spends a v_add_u32 per read on adding the LDS
+// symbol's zero), the reads of chunk k + 1 issued before the fmas of chunk k, the source order pinned by scheduling fences
+// that only matrix and scalar instructions may cross -- hipcc's own counted lgkmcnt waits then leave the younger reads in
+// flight.  The final fma is asm with the result in x's own register: left to itself hipcc pairs two of them into a
+// v_pk_fma_f32 behind three v_mov_b32, or (as v_fmac_f32) leaves each result in one half of the 64-bit pair the read
+// returned, which fragments the register file into 60-80 spills.  (A first form issued eight reads and waited for them
+// inside one asm statement: 5 % slower on both kernels -- the LDS round trip of every chunk was exposed.)
+#ifndef BALF_S1_GELU_CH
+#define BALF_S1_GELU_CH 8
+#endif
+template <int CH>
+__device__ __forceinline__ void gelu_lut_pipe(f4 (&t)[2][4], float magic) {
+    constexpr int NCH = 32 / CH;
+    typedef const f2 __attribute__((address_space(3))) *lds_f2_ptr;
+    float v[32];
 #pragma unroll
-    for (int i = 0; i < N; ++i) o[i] = gelu_lut_off(x[i], magic);
-    f2 ab[N];
-    if constexpr (N == 8)
-        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
-                     "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(ab[0]), "=&v"(ab[1]), "=&v"(ab[2]), "=&v"(ab[3]), "=&v"(ab[4]), "=&v"(ab[5]), "=&v"(ab[6]), "=&v"(ab[7])
-                     : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]));
-    else
-        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(ab[0]), "=&v"(ab[1]), "=&v"(ab[2]), "=&v"(ab[3])
-                     : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+    for (int i = 0; i < 32; ++i) v[i] = t[i >> 4][(i >> 2) & 3][i & 3];
+    auto fence = [] { __builtin_amdgcn_sched_barrier(0x8 | 0x4); };          // MFMA and SALU may cross, VALU and LDS not
+    f2 ab[2][CH];
+    auto issue = [&](int c, int buf) {
 #pragma unroll
-    for (int i = 0; i < N; ++i)      // (asm: the result goes into x's register)
-        asm("v_fma_f32 %0, %1, %0, %2" : "+v"(x[i]) : "v"(ab[i][1]), "v"(ab[i][0]));
+        for (int i = 0; i < CH; ++i) ab[buf][i] = *reinterpret_cast<lds_f2_ptr>(gelu_lut_off(v[c * CH + i], magic));
+    };
+    auto finish = [&](int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            asm("v_fma_f32 %0, %1, %0, %2" : "+v"(v[c * CH + i]) : "v"(ab[buf][i][1]), "v"(ab[buf][i][0]));
+    };
+    issue(0, 0);
+    fence();
+#pragma unroll
+    for (int c = 1; c < NCH; ++c) {
+        issue(c, c & 1);
+        fence();
+        finish(c - 1, (c - 1) & 1);
+        fence();
+    }
+    finish(NCH - 1, (NCH - 1) & 1);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t[i >> 4][(i >> 2) & 3][i & 3] = v[i];
 }
 
-template <int CHUNK, int NT, int P>
-__device__ __forceinline__ void s1_gelu(f4 (&t)[NT][P]) {
+__device__ __forceinline__ void s1_gelu(f4 (&t)[2][4]) {
 #if BALF_GELU_LUT
     if (BALF_ABLATE_GELU) return;
     float magic = 12582912.0f;                   // 1.5 * 2^23, kept in a vector register (the fma's other two operands use the constant bus)
     asm("" : "+v"(magic));
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int p = 0; p < P; p += CHUNK / 4) {
-            float v[CHUNK];
-#pragma unroll
-            for (int i = 0; i < CHUNK; ++i) v[i] = t[nt][p + (i >> 2)][i & 3];
-            gelu_lut_n(v, magic);
-#pragma unroll
-            for (int i = 0; i < CHUNK; ++i) t[nt][p + (i >> 2)][i & 3] = v[i];
-        }
+    gelu_lut_pipe<BALF_S1_GELU_CH>(t, magic);
 #else
     gelu<false>(t);
 #endif
@@ -270,7 +272,6 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     constexpr int C = kS1C, P = 4, NW = s1_waves<MODE>(), NTHR = NW * 64;
     constexpr int BM = MODE == 0 ? 0 : 1;                        // branch whose weights / token geometry this kernel uses
     constexpr bool TAIL = MODE == 2;                             // the stage's tail (see the loop body)
-    constexpr int kGeluChunk = MODE == 0 ? BALF_S1_GELU_CHUNK0 : 8; (void)kGeluChunk;   // table reads in flight per wave (registers: 3 per value)
     constexpr int STAMP_KID = BM; (void)STAMP_KID;
     STAMP_DECL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         f4 z[2][P];                                              // u (grid) / v (block): kept for the branch residual
         s1_bias(z, par + kS1pQ1B, q);
         s1_linear(z, wl + kS1Q1, 2048, b);
-        s1_gelu<kGeluChunk>(z);
+        s1_gelu(z);
         STAMP(3);   // dense1 half + GELU
         s1_ln_split(z, b);
         STAMP(4);   // LN + split
@@ -561,13 +562,13 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         f4 ga[2][P];
         s1_bias(ga, par + kS1pD1B, q);
         s1_linear(ga, wl + kS1D1, 2048, b);
-        s1_gelu<kGeluChunk>(ga);
+        s1_gelu(ga);
         STAMP(5);   // branch dense1 (a half) + GELU
         {
             f4 gb[2][P];
             s1_bias(gb, par + kS1pD1B + C, q);
             s1_linear(gb, wl + kS1D1 + 2 * 2048, 2048, b);
-            s1_gelu<kGeluChunk>(gb);
+            s1_gelu(gb);
             // gating LayerNorm (affine) -> transposed token tile bT[hi|lo][c][t], t = 4 li + p: 8-byte stores
             float rstd[P], shift[P];
 #pragma unroll
