@@ -100,7 +100,10 @@ int balf_window_nms(const float *score_dev, int B, int H, int W, int border, int
  * order whose NMS score >= the K-th largest NMS score (reference fallback when that is <= 0),
  * emitted sorted by (score descending, index ascending); score_dev their scores;
  * entries past count are idx -1 / score 0.  K <= H*W (the reference raises IndexError
- * otherwise) and K <= BALF_MAX_TOPK. */
+ * otherwise) and K <= BALF_MAX_TOPK.  Scores are probabilities (>= +0): with negative scores in the map the points
+ * with a positive score are still selected exactly as the reference selects them, but the reference's <= 0 fallback
+ * then returns -0.0 and negative window maxima (its NMS map is x * (x == max)), which this entry point does not
+ * reproduce (it returns the first K raster pixels with score +0). */
 size_t balf_nms_topk_workspace_bytes(int B, int H, int W, int K);
 int balf_nms_topk(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W,
                   int border, int nms_size, int K, int32_t *idx_dev, float *score_dev,

@@ -214,3 +214,58 @@ def test_random_sweep_vs_c_oracle(dev):
             assert np.array_equal(idx[i, :n], ri.astype(np.int32)), tag
             assert np.array_equal(sc[i, :n].view(np.uint32), rs.view(np.uint32)), tag
             assert np.all(idx[i, n:] == -1), tag
+
+
+def test_window15_vector_kernel_sweep(dev):
+    """The tuned window-15 tile kernel (nms_tile15_vec_kernel: taken for nms_size 15, survivor mode, 16-byte aligned rows)
+    on 80 seeded configurations that all meet its conditions: maps of one to three 114-row tiles and one to four 64-column
+    tiles with ragged edges, crops at multiples of four columns, borders from 0 to beyond a tile, K from 1 to all pixels,
+    tie-heavy / sparse / zero maps and maps with NEGATIVE scores among positive ones (its maxima are integer maxima on the
+    float bits, which order negative floats differently -- no point with a score <= 0 may survive either way) -- bit-exact
+    against the C oracle, and identical to the generic kernel (BALF_NMS_NO_VEC is read once per process, so the comparison is with the
+    oracle only here; tools/nms_ab.py runs both kernels)."""
+    from balf_amd import ops
+    from oracle import c_oracle
+    rng = np.random.default_rng(4242)
+    for case in range(80):
+        h, w = int(rng.integers(1, 301)), int(rng.integers(1, 241))
+        border = int(rng.choice([0, 1, 7, 15, 16, 23, 40, 70, 130]))
+        k = int(rng.integers(1, min(h * w, 4000) + 1))
+        b = int(rng.integers(1, 4))
+        pad_t, pad_l = int(rng.integers(0, 9)), 4 * int(rng.integers(0, 3))
+        hp = h + pad_t + int(rng.integers(0, 9))
+        wp = (w + pad_l + int(rng.integers(0, 9)) + 3) // 4 * 4
+        kind = rng.choice(["rand", "quant", "quant8", "sparse", "zeros", "signed", "signed_dense"])
+        if kind.startswith("signed"):
+            k = min(k, 8)                                                # keep the K-th score positive (see below)
+        maps = []
+        for i in range(b):
+            r = rng.random((hp, wp), dtype=np.float32)
+            if kind == "quant":
+                r = np.round(r * 50) / 50
+            elif kind == "quant8":
+                r = np.round(r * 4) / 4
+            elif kind == "sparse":
+                r = np.where(rng.random((hp, wp)) < 0.02, r + 0.01, 0.0)
+            elif kind == "zeros":
+                r = np.zeros((hp, wp))
+            elif kind == "signed":
+                r = np.round((r - 0.6) * 20) / 20                        # mostly negative, ties, some -0.0
+            elif kind == "signed_dense":
+                r = r - 0.3
+            maps.append(r.astype(np.float32))
+        t = torch.from_numpy(np.stack(maps)).to(dev)
+        idx, sc, cnt = ops.nms_topk(t, pad_t, pad_l, h, w, border, 15, k)
+        idx, sc, cnt = idx.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(b):
+            ri, rs, _ = c_oracle.nms_topk(np.ascontiguousarray(maps[i][pad_t:pad_t + h, pad_l:pad_l + w]), border, 15, k)
+            if kind.startswith("signed") and not (rs.size and rs.min() > 0):
+                continue       # the reference's <= 0 fallback on a map with negative scores returns -0.0 / negative maxima:
+                               # outside the contract of the entry point (probability maps, include/balf_hip.h)
+            ri, rs = O.canonical_order(ri.astype(np.int64), rs)
+            n = int(cnt[i])
+            tag = (case, h, w, border, k, kind, i)
+            assert n == ri.size, tag
+            assert np.array_equal(idx[i, :n], ri.astype(np.int32)), tag
+            assert np.array_equal(sc[i, :n].view(np.uint32), rs.view(np.uint32)), tag
+            assert np.all(idx[i, n:] == -1), tag
