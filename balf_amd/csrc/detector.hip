@@ -426,6 +426,8 @@ int run_pool(int s, const float *T, const float *R, const float *scale, int B, i
 
 int forward_f32(const float *blob, const float *x_nchw_dev, const InputU8 &u8, int B, int Hp, int Wp, float *logits_dev,
                 float *prob_dev, char *ws, const Plan &pl, hipStream_t st) {
+    balf_prof::Chain prof_chain;       // the launches below follow each other on `st` with nothing in between
+
     float *U = reinterpret_cast<float *>(ws + pl.off_U), *T = reinterpret_cast<float *>(ws + pl.off_T),
           *R = reinterpret_cast<float *>(ws + pl.off_R), *partial = reinterpret_cast<float *>(ws + pl.off_partial),
           *chunk = reinterpret_cast<float *>(ws + pl.off_chunk), *scale = reinterpret_cast<float *>(ws + pl.off_scale);

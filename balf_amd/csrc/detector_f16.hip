@@ -1767,6 +1767,8 @@ extern "C" int balf_debug_stamps(unsigned long long *sums /*[16*40]*/, unsigned 
 
 int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, int B, int Hp, int Wp, float *logits_dev,
                 float *prob_dev, char *ws, const Plan &pl, hipStream_t st) {
+    balf_prof::Chain prof_chain;       // the launches below follow each other on `st` with nothing in between
+
     float *U = reinterpret_cast<float *>(ws + pl.off_U), *T = reinterpret_cast<float *>(ws + pl.off_T),
           *R = reinterpret_cast<float *>(ws + pl.off_R), *partial = reinterpret_cast<float *>(ws + pl.off_partial),
           *chunk = reinterpret_cast<float *>(ws + pl.off_chunk), *scale = reinterpret_cast<float *>(ws + pl.off_scale);

@@ -26,6 +26,15 @@ enum Slot {
 extern bool g_on;
 void before(int slot, hipStream_t st);
 void after(hipStream_t st);
+// Between chain_begin() and chain_end() the caller issues its launches back to back on one stream with nothing else in
+// between (the detector forward): consecutive kernels then share one time stamp -- the end of kernel k is the start of
+// kernel k + 1 -- instead of two events per launch.
+void chain_begin();
+void chain_end();
+struct Chain {
+    Chain() { if (g_on) chain_begin(); }
+    ~Chain() { if (g_on) chain_end(); }
+};
 }  // namespace balf_prof
 
 #define BALF_PROF(slot, stream, launch_stmt)                       \

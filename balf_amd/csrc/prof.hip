@@ -15,6 +15,12 @@ size_t g_used = 0;
 std::vector<Rec> g_recs;
 hipEvent_t g_pending = nullptr;
 int g_pending_slot = -1;
+// the `after` stamp of the previous launch of the current chain (launches issued back to back on one stream by one
+// entry point, nothing else in between): the next launch of the chain takes it as its `before` stamp instead of
+// recording another event -- an event record costs the stream ~4 us, 0.55 ms per 32-image step with a pair per launch
+hipEvent_t g_chain_last = nullptr;
+hipStream_t g_chain_stream = nullptr;
+bool g_chain_on = false;
 
 hipEvent_t take_event() {
     if (g_used == g_pool.size()) {
@@ -26,18 +32,28 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
+void chain_begin() { g_chain_last = nullptr; g_chain_on = true; }
+void chain_end() { g_chain_last = nullptr; g_chain_on = false; }
+
 void before(int slot, hipStream_t st) {
-    g_pending = take_event();
     g_pending_slot = slot;
+    if (g_chain_on && g_chain_last && g_chain_stream == st) {
+        g_pending = g_chain_last;
+        return;
+    }
+    g_pending = take_event();
     if (g_pending) (void)hipEventRecord(g_pending, st);
 }
 
 void after(hipStream_t st) {
     hipEvent_t e = take_event();
+    g_chain_last = nullptr;
     if (!g_pending || !e) return;
     (void)hipEventRecord(e, st);
     g_recs.push_back({g_pending_slot, g_pending, e});
     g_pending = nullptr;
+    g_chain_last = e;
+    g_chain_stream = st;
 }
 
 }  // namespace balf_prof
@@ -58,6 +74,7 @@ extern "C" const char *balf_profile_slot_name(int slot) {
 }
 
 extern "C" int balf_profile_begin(void) {
+    balf_prof::chain_end();
     balf_prof::g_recs.clear();
     balf_prof::g_used = 0;
     balf_prof::g_on = true;
