@@ -30,13 +30,14 @@ namespace balf {
 namespace {
 
 // two accumulator tiles (channels 16*2s + 4q + r and 16*(2s+1) + 4q + r) -> one K-step B fragment
+template <int MIX = BALF_SPLIT_MIX>
 __device__ __forceinline__ HL split8(const f4 &t0, const f4 &t1) {
     HL o;
     h2 h, l;
-    split_pair(t0[0], t0[1], h, l); o.hi[0] = h[0]; o.hi[1] = h[1]; o.lo[0] = l[0]; o.lo[1] = l[1];
-    split_pair(t0[2], t0[3], h, l); o.hi[2] = h[0]; o.hi[3] = h[1]; o.lo[2] = l[0]; o.lo[3] = l[1];
-    split_pair(t1[0], t1[1], h, l); o.hi[4] = h[0]; o.hi[5] = h[1]; o.lo[4] = l[0]; o.lo[5] = l[1];
-    split_pair(t1[2], t1[3], h, l); o.hi[6] = h[0]; o.hi[7] = h[1]; o.lo[6] = l[0]; o.lo[7] = l[1];
+    split_pair<MIX>(t0[0], t0[1], h, l); o.hi[0] = h[0]; o.hi[1] = h[1]; o.lo[0] = l[0]; o.lo[1] = l[1];
+    split_pair<MIX>(t0[2], t0[3], h, l); o.hi[2] = h[0]; o.hi[3] = h[1]; o.lo[2] = l[0]; o.lo[3] = l[1];
+    split_pair<MIX>(t1[0], t1[1], h, l); o.hi[4] = h[0]; o.hi[5] = h[1]; o.lo[4] = l[0]; o.lo[5] = l[1];
+    split_pair<MIX>(t1[2], t1[3], h, l); o.hi[6] = h[0]; o.hi[7] = h[1]; o.lo[6] = l[0]; o.lo[7] = l[1];
     return o;
 }
 

@@ -43,6 +43,7 @@ __device__ __forceinline__ f4x mfma16x3(const HL &a, const HL &b, f4x c) {
 #ifndef BALF_SPLIT_MIX
 #define BALF_SPLIT_MIX 1
 #endif
+template <int MIX = BALF_SPLIT_MIX>
 __device__ __forceinline__ void split_pair(float v0, float v1, h2 &hi, h2 &lo) {
     if (BALF_ABLATE_SPLIT) {                       // timing experiment: one convert, no residual
         typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
@@ -53,7 +54,19 @@ __device__ __forceinline__ void split_pair(float v0, float v1, h2 &hi, h2 &lo) {
     typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
     const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);      // hi = rtz_f16(v); v - hi is exact in fp32
     hi = __builtin_bit_cast(h2, h);
-#if BALF_SPLIT_MIX
+    if constexpr (MIX == 2) {
+    // MIX == 2 (the stage-1 kernels): residuals in fp32 (v_fma_mix_f32 reads hi as f16: 4.9 cycles each against 8.9 for the
+    // f16-writing forms below), then one more packed convert -- lo is rounded toward zero instead of to nearest (2^-21
+    // instead of 2^-22 of v); each residual is built in the register of its own input (see the hazard note below).
+    // Measured per 8 x 1088x1920: stage-1 block 1.465 -> 1.42 ms, grid 1.12 -> 1.07; the channel-split kernels of stages 2-4
+    // (at their register limits) lose 1 % with it and keep MIX == 1.
+    const unsigned hu2 = __builtin_bit_cast(unsigned, h);
+    float r0 = v0, r1 = v1;
+    asm("v_fma_mix_f32 %0, %2, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %2, -1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "+v"(r0), "+v"(r1) : "v"(hu2));
+    lo = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+    } else if constexpr (MIX == 1) {
     // lo = f16(v - hi) straight from the packed halves: v_fma_mix{lo,hi}_f16 read hi as f16, v as f32, and write
     // one half of the destination each -- 3 instructions per pair instead of the 5 hipcc emits for the casts.
     // The result is built IN v0's REGISTER ("+v"): hipcc does not pad hazards around inline asm, and a free register
@@ -66,10 +79,10 @@ __device__ __forceinline__ void split_pair(float v0, float v1, h2 &hi, h2 &lo) {
         "v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
         : "+v"(lu) : "v"(hu), "v"(v1));
     lo = __builtin_bit_cast(h2, lu);
-#else
+    } else {
     const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(fmaf((float)hi[0], -1.0f, v0), fmaf((float)hi[1], -1.0f, v1));
     lo = __builtin_bit_cast(h2, l);
-#endif
+    }
 }
 
 

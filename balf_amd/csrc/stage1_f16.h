@@ -23,6 +23,9 @@
 #pragma once
 
 constexpr int kS1C = 32;
+#ifndef BALF_S1_SPLIT_MIX
+#define BALF_S1_SPLIT_MIX 2   // operand split form of the stage-1 kernels (split16.h)
+#endif
 // Transposed token tile of a wave (32 channels x 64 tokens, hi and lo planes of 4 KB): rows of 128 B whose eight 16-B
 // chunks are XOR-swizzled by the row, so that the 8-byte writes (a lane's four adjacent tokens of one channel) and the
 // 16-byte A-fragment reads (eight tokens of a row) both spread over the LDS banks without padding.
@@ -119,14 +122,14 @@ __device__ __forceinline__ void s1_ln_split(const f4 (&x)[2][P], HL (&b)[P]) {
             y0[r] = fmaf(x[0][p][r], rstd, shift);
             y1[r] = fmaf(x[1][p][r], rstd, shift);
         }
-        b[p] = split8(y0, y1);
+        b[p] = split8<BALF_S1_SPLIT_MIX>(y0, y1);
     }
 }
 
 template <int P>
 __device__ __forceinline__ void s1_split(const f4 (&x)[2][P], HL (&b)[P]) {
 #pragma unroll
-    for (int p = 0; p < P; ++p) b[p] = split8(x[0][p], x[1][p]);
+    for (int p = 0; p < P; ++p) b[p] = split8<BALF_S1_SPLIT_MIX>(x[0][p], x[1][p]);
 }
 
 // acc[nt][p] (+)= W(row tile nt) . B[p]: one K-step, weight fragments from the LDS image (wl already + lane * 16)
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
                 o1[r] = lane_select(selm, mx[1][1][r], mx[1][0][r]);
             }
             const long opix = ((long)g.n * (H / 2) + (g.y >> 1)) * (W / 2) + (g.x0 >> 1) + sel;
-            store_frag_px(A.out, opix, C, 0, q, split8(o0, o1));
+            store_frag_px(A.out, opix, C, 0, q, split8<BALF_S1_SPLIT_MIX>(o0, o1));
         } else {
         f4 x0k[(MODE == 1 && BALF_S1_KEEP_X0) ? 2 : 1][(MODE == 1 && BALF_S1_KEEP_X0) ? P : 1];   // (block) x0, kept for x1 = . + x0
         if constexpr (MODE == 1 && BALF_S1_KEEP_X0) {
@@ -583,8 +586,8 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
 #pragma unroll
                     for (int p = 0; p < P; ++p) v[p] = fmaf(fmaf(gb[nt][p][r], rstd[p], shift[p]), gg[r], bb[r]);
                     h2 h01, l01, h23, l23;
-                    split_pair(v[0], v[1], h01, l01);
-                    split_pair(v[2], v[3], h23, l23);
+                    split_pair<BALF_S1_SPLIT_MIX>(v[0], v[1], h01, l01);
+                    split_pair<BALF_S1_SPLIT_MIX>(v[2], v[3], h23, l23);
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                     unsigned char *row = bT + s1_bt_wr(16 * nt + 4 * q + r, li);
                     *reinterpret_cast<h4 *>(row) = h4{h01[0], h01[1], h23[0], h23[1]};
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         STAMP(8);   // dense2 + residual
         if constexpr (MODE == 0) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) store_frag_px(A.U, pix0 + p * pstep, C, 0, q, split8(o[0][p], o[1][p]));
+            for (int p = 0; p < P; ++p) store_frag_px(A.U, pix0 + p * pstep, C, 0, q, split8<BALF_S1_SPLIT_MIX>(o[0][p], o[1][p]));
             STAMP(9);   // u' store
         } else {
             s1_split(o, b);

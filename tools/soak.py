@@ -18,5 +18,8 @@ with torch.inference_mode():
         o = m(x)
         if not (torch.equal(o["prob"], ref["prob"]) and torch.equal(o["logits"], ref["logits"])):
             bad += 1
-            print("mismatch at repetition", i, int((o["prob"] != ref["prob"]).sum()))
+            d = (o["prob"] != ref["prob"])
+            w = d.nonzero()
+            print("mismatch at repetition", i, int(d.sum()), "differing score-map values; max abs diff %.3e" % float((o["prob"] - ref["prob"]).abs().max()),
+                  "first at (image, y, x)", w[0].tolist() if len(w) else None, "last", w[-1].tolist() if len(w) else None, flush=True)
 print(f"{reps} repetitions of {b}x{h}x{w}: {bad} mismatches, finite={bool(torch.isfinite(ref['prob']).all())}")
