@@ -15,6 +15,8 @@ with torch.inference_mode():
     ref = m(x)
     bad = 0
     for i in range(reps):
+        if i and i % 5000 == 0:
+            print(f"  ... {i} repetitions, {bad} mismatches so far", flush=True)
         o = m(x)
         if not (torch.equal(o["prob"], ref["prob"]) and torch.equal(o["logits"], ref["logits"])):
             bad += 1
