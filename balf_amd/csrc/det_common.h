@@ -175,11 +175,15 @@ __device__ __forceinline__ void lrelu(f4 (&t)[NT][P]) {
         for (int p = 0; p < P; ++p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = t[nt][p][r];
+                float v = t[nt][p][r];
                 // = v > 0 ? v : 0.2 v (slope < 1) in two instructions: the compiler's fmaxf first canonicalises v
-                // (a third instruction); m is an arithmetic result and v has been read by the multiply before
+                // (a third instruction); m is an arithmetic result and v has been read by the multiply before.  The
+                // result is written into v's OWN register ("+v"), never into a fresh one: hipcc does not pad hazards
+                // around inline asm, and a free register can be the SrcC of an MFMA (of an independent Linear the
+                // scheduler hoisted) still in flight -- see split16.h
                 const float m = 0.2f * v;
-                asm("v_max_f32 %0, %1, %2" : "=v"(t[nt][p][r]) : "v"(v), "v"(m));
+                asm("v_max_f32 %0, %0, %1" : "+v"(v) : "v"(m));
+                t[nt][p][r] = v;
             }
 }
 

@@ -57,8 +57,8 @@ template <int MODE> constexpr int cs_lut_bytes() { return cs_gelu_lut<MODE>() ? 
 // s = clamp01((|x| + 1) / 8) names with its low two exponent bits and top eight mantissa bits:
 //   s          v_fma_f32 |x|, 1/8, 1/8 clamp     (the compiler's instruction: x is an MFMA result, see stage1_f16.h)
 //   off        (bits(s) >> 12) & 0x1FF8          byte offset of the (A, B) pair; s = 1 (|x| >= 7) names the asymptote entry
-//   gelu       fma(0.5, x, fma(B, |x|, A))
-// 5 vector instructions (17 issue cycles at the measured class rates) + 1 LDS read against 8 (33) for the 2^P form.
+//   gelu       x / 2 + fma(B, |x|, A)
+// 6 vector instructions (20 issue cycles at the measured class rates) + 1 LDS read against 8 (33) for the 2^P form.
 template <int N>
 __device__ __forceinline__ void gelu_log_n(float (&x)[N]) {
     static_assert(N == 4 || N == 8, "");
@@ -84,8 +84,13 @@ __device__ __forceinline__ void gelu_log_n(float (&x)[N]) {
                      : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        float e;
-        asm("v_fma_f32 %1, %2, |%0|, %3\n\tv_fma_f32 %0, 0.5, %0, %1" : "+v"(x[i]), "=&v"(e) : "v"(ab[i][1]), "v"(ab[i][0]));
+        // x / 2 by the compiler, E = B |x| + A as asm IN x's OWN REGISTER, the sum by the compiler.  No inline-asm write
+        // into a fresh register: such a write can land on the SrcC of an MFMA of the next Linear that hipcc hoisted in
+        // front of it (split16.h) -- hipcc pads that hazard for its own instructions only.  (Both fmas left to hipcc: it
+        // pairs them into v_pk_fma_f32 behind 100 extra v_mov_b32 per wave.)
+        const float half = 0.5f * x[i];
+        asm("v_fma_f32 %0, %1, |%0|, %2" : "+v"(x[i]) : "v"(ab[i][1]), "v"(ab[i][0]));
+        x[i] += half;
     }
 }
 

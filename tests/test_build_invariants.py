@@ -72,3 +72,24 @@ def test_table_gelu_kernels_have_no_static_lds(tmp_path):
     for n in names:
         assert meta[n]["group_segment_fixed_size"] == 0, (n, meta[n])
         assert meta[n]["vgpr_spill_count"] == 0, (n, meta[n])
+
+
+def test_no_inline_asm_valu_writes_fresh_register():
+    """Source lint.  hipcc pads the MFMA hazards (a VALU write within a few wait states of an MFMA that still reads the
+    register as SrcC corrupts the accumulator input) for its own instructions only.  An inline-asm VALU instruction must
+    therefore write the register of one of its own live inputs ("+v"), never a fresh output ("=v" / "=&v"), which the
+    register allocator may place on the SrcC of an MFMA the scheduler hoisted in front of it (split16.h, DESIGN 4.3b/4.3d:
+    found twice as rare non-deterministic errors)."""
+    src = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc")
+    bad = []
+    for name in sorted(os.listdir(src)):
+        if not name.endswith((".h", ".hip")):
+            continue
+        text = open(os.path.join(src, name)).read()
+        for m in re.finditer(r'\basm\s*(?:volatile)?\s*\(\s*((?:"(?:[^"\\]|\\.)*"\s*)+):([^:;]*)', text):
+            template, outputs = m.group(1), m.group(2)
+            if re.search(r'"\s*v_', template) is None and re.search(r'\\t\s*v_', template) is None:
+                continue                                    # no vector-ALU instruction in this statement
+            if re.search(r'"=&?v"', outputs):
+                bad.append((name, text[:m.start()].count("\n") + 1, template.strip()[:60]))
+    assert not bad, bad
