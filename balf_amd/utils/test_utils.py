@@ -131,3 +131,45 @@ def get_points_direct_from_score_map(heatmap, conf_thresh=0.015, nms_size=15, su
         raise ValueError(order_coord)
     out[:, 2], out[:, 3] = scale_value, score[0, :n].cpu().numpy()
     return out
+
+
+def nms_fast(in_corners, H, W, dist_thresh):
+    """Mirror of the stand-alone greedy NMS on a corner list (/root/reference/balf/utils/test_utils.py:130-168,
+    SuperPoint's ``nms_fast``): ``in_corners`` is ``3 x N`` ``[x, y, confidence]``; returns ``(out 3 x M, out_inds M)``
+    -- the surviving corners sorted by confidence and their indices into ``in_corners``.
+
+    The sweep itself runs in ``balf_greedy_nms`` on a rasterised map whose values are the corners' RANKS in the
+    confidence order (exact in fp32 up to 2^24 corners, so that the suppression order is the reference's order whatever
+    the confidences' precision); everything else is index bookkeeping on the host, quirks included: coordinates are
+    rounded half-to-even, a cell holding several corners takes part with the best of them but REPORTS the worst one
+    (the reference's ``inds`` grid keeps the last writer).  Among exactly equal confidences the order is the stable one
+    (NumPy's default argsort, which the reference uses, is unstable there)."""
+    in_corners = np.asarray(in_corners)
+    n = in_corners.shape[1]
+    inds1 = np.argsort(-in_corners[2, :], kind="stable")
+    corners = in_corners[:, inds1]
+    rcorners = corners[:2, :].round().astype(int)
+    if n == 0:
+        return np.zeros((3, 0)).astype(int), np.zeros(0).astype(int)
+    if n == 1:
+        return np.vstack((rcorners, in_corners[2])).reshape(3, 1), np.zeros((1)).astype(int)
+    if rcorners[0].min() < 0 or rcorners[0].max() >= W or rcorners[1].min() < 0 or rcorners[1].max() >= H:
+        raise IndexError("corner outside the H x W grid")
+    if n >= 1 << 24:
+        raise NotImplementedError("more than 2^24 corners")
+    flat = rcorners[1].astype(np.int64) * W + rcorners[0]
+    rank_map = np.zeros(H * W, dtype=np.float32)
+    np.maximum.at(rank_map, flat, np.arange(n, 0, -1, dtype=np.float32))    # a cell takes part with its best corner: n - position
+    inds = np.zeros(H * W, dtype=np.int64)
+    np.maximum.at(inds, flat, np.arange(n))                                 # ... and reports its worst one (the reference's last writer)
+    t = torch.from_numpy(rank_map.reshape(1, H, W)).to(_device())
+    k = min(ops._lib.MAX_TOPK, H * W)
+    idx, _, _, count, total = ops.greedy_nms(t, 0, 0, H, W, 0, 0.5, int(dist_thresh), k, 0)
+    m = int(count[0])
+    if int(total[0]) > m:
+        raise NotImplementedError(f"{int(total[0])} corners survive, more than the {k} the kernel returns")
+    keep = np.sort(idx[0, :m].cpu().numpy().astype(np.int64))               # raster order, as np.where gives it
+    inds_keep = inds[keep]
+    out = corners[:, inds_keep]
+    inds2 = np.argsort(-out[-1, :], kind="stable")
+    return out[:, inds2], inds1[inds_keep[inds2]]

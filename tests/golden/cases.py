@@ -95,6 +95,21 @@ GREEDY_CASES = {
 }
 
 
+# stand-alone nms_fast on a corner list: name -> (H, W, number of corners, dist_thresh, seed); float coordinates, distinct
+# confidences, several corners per cell in the dense cases
+NMS_FAST_CASES = {"c_sparse": (120, 160, 300, 4, 31), "c_dense": (60, 80, 3000, 4, 32), "c_wide": (200, 150, 2000, 9, 33),
+                  "c_two": (40, 40, 2, 3, 34), "c_one": (40, 40, 1, 3, 35), "c_none": (40, 40, 0, 3, 36)}
+
+
+def nms_fast_input(h, w, n, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-0.49, w - 0.51, n)
+    y = rng.uniform(-0.49, h - 0.51, n)
+    c = rng.permutation(n).astype(np.float64) / max(n, 1) + 0.01             # distinct confidences
+    return np.stack([x, y, c]) if n else np.zeros((3, 0))
+
+
 # HardNet descriptor cases: name -> (number of patches, patch seed); weights = synthetic_hardnet_state_dict(HARDNET_SEED)
 HARDNET_SEED = 515
 HARDNET_CASES = {"n5": (5, 1), "n70": (70, 2)}

@@ -157,6 +157,14 @@ def main():
             gk[name + ".score"] = pts[:, 3].astype(np.float32)      # emitted sorted by confidence, descending
     np.savez_compressed(os.path.join(HERE, "greedy_nms.npz"), **gk)
 
+    # ---------------- stand-alone nms_fast on a corner list ----------------
+    ck = {}
+    for name, (h, w, n, dist, seed) in cases.NMS_FAST_CASES.items():
+        out, out_inds = RT.nms_fast(cases.nms_fast_input(h, w, n, seed), h, w, dist)
+        ck[name + ".out"] = np.asarray(out, dtype=np.float64)
+        ck[name + ".inds"] = np.asarray(out_inds, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "nms_fast.npz"), **ck)
+
     # ---------------- HardNet descriptor (demo path) ----------------
     hn = HardNet().eval()
     hsd = synth.synthetic_hardnet_state_dict(cases.HARDNET_SEED)

@@ -81,3 +81,17 @@ def test_greedy_random_sweep_vs_oracle():
         assert n == len(ri) == int(tot[0]), tag
         assert np.array_equal(idx[0, :n].cpu().numpy(), np.asarray(ri, np.int32)), tag
         assert np.array_equal(sc[0, :n].cpu().numpy().view(np.uint32), np.asarray(rs, np.float32).view(np.uint32)), tag
+
+
+@pytest.mark.parametrize("name", list(cases.NMS_FAST_CASES))
+def test_nms_fast_corner_list_golden(name):
+    """The stand-alone ``nms_fast`` on a corner list (reference test_utils.py:130-168; goldens recorded from the
+    reference's own function): same surviving corners, same order, same indices -- float coordinates, several corners per
+    cell (the reference reports the WORST corner of a cell that wins with its best one), 0 / 1 / 2 corners."""
+    from balf_amd.utils import test_utils as T
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "nms_fast.npz"))
+    h, w, n, dist, seed = cases.NMS_FAST_CASES[name]
+    out, inds = T.nms_fast(cases.nms_fast_input(h, w, n, seed), h, w, dist)
+    assert out.shape == f[name + ".out"].shape
+    assert np.array_equal(np.asarray(out, dtype=np.float64), f[name + ".out"])
+    assert np.array_equal(np.asarray(inds, dtype=np.int64), f[name + ".inds"])
