@@ -104,7 +104,8 @@ def get_points_direct_from_score_map(heatmap, conf_thresh=0.015, nms_size=15, su
     threshold, greedy ``nms_fast`` with a (2*nms_size+1)^2 suppression window, sort by confidence, optional
     sub-pixel soft-argmax -> rows ``[x, y, scale, score]`` float64 (``np.zeros((0, 4))`` when nothing passes).
     Among exactly equal scores the raster-first point wins (the reference's order there is NumPy's unstable
-    argsort).  The sub-pixel step follows torchgeometry's documented soft-argmax (parity unpinned)."""
+    argsort).  The sub-pixel step is pinned against the reference's own code around its one torchgeometry call (that call:
+    documented definition, unpinned; tests/golden/subpixel.npz)."""
     m = _as_map(heatmap)
     h, w = m.shape
     t = torch.from_numpy(m).to(_device()).unsqueeze(0)

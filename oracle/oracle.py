@@ -254,7 +254,8 @@ def greedy_nms(heatmap: np.ndarray, conf_thresh: float, dist_thresh: int) -> Tup
 def soft_argmax_refine(heatmap: np.ndarray, idx: np.ndarray, patch: int) -> np.ndarray:
     """``soft_argmax_points`` (test_utils.py:170-215) by its definition: the patch, normalised by its sum + 1e-6,
     log-ed and soft-max-ed (= the patch re-normalised), gives the expected (x, y); p += E - patch//2.
-    PARITY UNPINNED: torchgeometry (SpatialSoftArgmax2d) is not installed in the build container."""
+    Pinned (tests/golden/subpixel.npz) against the reference's own code run around a restatement of its one torchgeometry
+    call, SpatialSoftArgmax2d (not installed in the build container; that call itself stays unpinned)."""
     h, w = heatmap.shape
     pad = patch // 2
     hp = np.pad(heatmap.astype(np.float64), pad, mode="constant")

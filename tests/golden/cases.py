@@ -95,6 +95,9 @@ GREEDY_CASES = {
 }
 
 
+# sub-pixel refinement: (greedy case, patch size); 5 is the reference's default, 4 an even size (asymmetric patch)
+SUBPIXEL_CASES = [("g_rand_96x128", 5), ("g_blobs_240x320", 5), ("g_small_radius", 5), ("g_blobs_240x320", 4), ("g_sparse", 3)]
+
 # stand-alone nms_fast on a corner list: name -> (H, W, number of corners, dist_thresh, seed); float coordinates, distinct
 # confidences, several corners per cell in the dense cases
 NMS_FAST_CASES = {"c_sparse": (120, 160, 300, 4, 31), "c_dense": (60, 80, 3000, 4, 32), "c_wide": (200, 150, 2000, 9, 33),

@@ -157,6 +157,51 @@ def main():
             gk[name + ".score"] = pts[:, 3].astype(np.float32)      # emitted sorted by confidence, descending
     np.savez_compressed(os.path.join(HERE, "greedy_nms.npz"), **gk)
 
+    # ---------------- sub-pixel refinement of the demo path ----------------
+    # torchgeometry (requirements.txt:7, ">=0.1.2", not installed and not installable offline) supplies ONE call of this
+    # path, contrib.SpatialSoftArgmax2d (test_utils.py:198-201).  Everything around it -- threshold, nms_fast, the patch
+    # extraction with its padding and truncation, norm_patches, do_log, the coordinate update -- is the reference's own code
+    # and is executed here unchanged; the one missing call is supplied by the restatement below of its published definition
+    # (torchgeometry 0.1.2, contrib/spatial_soft_argmax2d.py: soft-max over the flattened patch with the max-subtraction
+    # trick and eps = 1e-6 in the normaliser, expectation of the pixel grid, output (x, y)).  So these vectors pin the
+    # reference's side of the sub-pixel path; the third-party call itself stays unpinned.
+    import types
+
+    class SpatialSoftArgmax2d(torch.nn.Module):
+        def __init__(self, normalized_coordinates=True):
+            super().__init__()
+            self.normalized_coordinates = normalized_coordinates
+            self.eps = 1e-6
+
+        def forward(self, input):
+            b, c, hh, ww = input.shape
+            x = input.view(b, c, -1)
+            exp_x = torch.exp(x - torch.max(x, dim=-1, keepdim=True)[0])
+            exp_x_sum = 1.0 / (exp_x.sum(dim=-1, keepdim=True) + self.eps)
+            if self.normalized_coordinates:
+                xs, ys = torch.linspace(-1, 1, ww), torch.linspace(-1, 1, hh)
+            else:
+                xs, ys = torch.linspace(0, ww - 1, ww), torch.linspace(0, hh - 1, hh)
+            pos_y, pos_x = torch.meshgrid(ys, xs, indexing="ij")
+            pos_x, pos_y = pos_x.reshape(-1).to(input.dtype), pos_y.reshape(-1).to(input.dtype)
+            expected_y = torch.sum((pos_y * exp_x) * exp_x_sum, dim=-1, keepdim=True)
+            expected_x = torch.sum((pos_x * exp_x) * exp_x_sum, dim=-1, keepdim=True)
+            return torch.cat([expected_x, expected_y], dim=-1).view(b, c, 2)
+
+    tgm = types.ModuleType("torchgeometry")
+    tgm.contrib = types.ModuleType("torchgeometry.contrib")
+    tgm.contrib.SpatialSoftArgmax2d = SpatialSoftArgmax2d
+    sys.modules["torchgeometry"], sys.modules["torchgeometry.contrib"] = tgm, tgm.contrib
+    sk = {}
+    for name, patch in cases.SUBPIXEL_CASES:
+        spec = cases.GREEDY_CASES[name]
+        rb = RT.remove_borders(cases.nms_input(spec), borders=spec["border"])
+        pts = RT.get_points_direct_from_score_map(heatmap=rb, conf_thresh=spec["conf"], nms_size=spec["nms"],
+                                                  subpixel=True, patch_size=patch, order_coord="xysr")
+        sk[f"{name}.p{patch}"] = np.asarray(pts, dtype=np.float64)          # rows [x, y, 1, score]
+    del sys.modules["torchgeometry"], sys.modules["torchgeometry.contrib"]
+    np.savez_compressed(os.path.join(HERE, "subpixel.npz"), **sk)
+
     # ---------------- stand-alone nms_fast on a corner list ----------------
     ck = {}
     for name, (h, w, n, dist, seed) in cases.NMS_FAST_CASES.items():

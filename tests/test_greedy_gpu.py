@@ -95,3 +95,24 @@ def test_nms_fast_corner_list_golden(name):
     assert out.shape == f[name + ".out"].shape
     assert np.array_equal(np.asarray(out, dtype=np.float64), f[name + ".out"])
     assert np.array_equal(np.asarray(inds, dtype=np.int64), f[name + ".inds"])
+
+
+@pytest.mark.parametrize("name,patch", cases.SUBPIXEL_CASES)
+def test_subpixel_against_reference_code(name, patch):
+    """Sub-pixel refinement of the demo path against vectors recorded from the REFERENCE'S OWN code
+    (get_points_direct_from_score_map(subpixel=True): threshold, nms_fast, patch extraction, norm_patches, do_log,
+    coordinate update -- test_utils.py:97-215) with its one third-party call, torchgeometry's SpatialSoftArgmax2d (not
+    installable offline), supplied by a restatement of the published definition (tests/golden/make_golden.py).  Pins the
+    reference's side of the path: same points, same order, same scores, coordinates within 2e-5 px (the reference runs that
+    part in fp32 torch, with torchgeometry's eps = 1e-6 in the soft-max normaliser)."""
+    from balf_amd.utils import test_utils as T
+    ref = np.load(os.path.join(G, "subpixel.npz"))[f"{name}.p{patch}"]
+    spec = cases.GREEDY_CASES[name]
+    rb = O.remove_borders(cases.nms_input(spec), spec["border"])
+    pts = T.get_points_direct_from_score_map(heatmap=rb, conf_thresh=spec["conf"], nms_size=spec["nms"], subpixel=True,
+                                             patch_size=patch, order_coord="xysr")
+    assert pts.shape == ref.shape
+    assert np.array_equal(pts[:, 3].astype(np.float32).view(np.uint32), ref[:, 3].astype(np.float32).view(np.uint32))
+    assert np.array_equal(pts[:, 2], ref[:, 2])
+    err = float(np.abs(pts[:, :2] - ref[:, :2]).max())
+    assert err < 2e-5, err

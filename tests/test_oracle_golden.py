@@ -131,6 +131,20 @@ def test_greedy_nms_cases(name):
     assert np.array_equal(sc.astype(np.float32).view(np.uint32), f[name + ".score"].view(np.uint32))
 
 
+@pytest.mark.parametrize("name,patch", cases.SUBPIXEL_CASES)
+def test_subpixel_refinement_cases(name, patch):
+    """O.soft_argmax_refine against the reference's own sub-pixel path (subpixel.npz: the reference's code around a
+    restated torchgeometry call, see make_golden.py): within 2e-5 px (fp32 torch + eps 1e-6 there, fp64 here)."""
+    ref = np.load(os.path.join(G, "subpixel.npz"))[f"{name}.p{patch}"]
+    spec = cases.GREEDY_CASES[name]
+    rb = O.remove_borders(cases.nms_input(spec), spec["border"])
+    idx, sc = O.greedy_nms(rb, spec["conf"], spec["nms"])
+    xy = O.soft_argmax_refine(rb, idx, patch)
+    assert xy.shape[0] == ref.shape[0]
+    assert np.array_equal(sc.astype(np.float32).view(np.uint32), ref[:, 3].astype(np.float32).view(np.uint32))
+    assert float(np.abs(xy - ref[:, :2]).max()) < 2e-5
+
+
 # ---------------- HardNet descriptor (SURVEY 8f row f3) ----------------
 def test_hardnet_oracle_matches_reference_goldens():
     """O.hardnet_forward against descriptors (and per-layer activations) recorded from the reference's own
