@@ -32,15 +32,21 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from balf_amd import arch, ops, pipeline  # noqa: E402
-from balf_amd.model import get_model  # noqa: E402
-from balf_amd.utils import synth  # noqa: E402
+
+def _import_product():
+    """torch, NumPy and the product package, imported only by a process that is going to be a rank: the launcher parent
+    of `--gpus N` (launch_ranks) must not load anything that could initialise the GPU (loading libbalf_hip.so registers
+    its code objects with the HIP runtime)."""
+    global np, torch, arch, ops, pipeline, get_model, synth
+    import numpy as np
+    import torch
+    from balf_amd import arch, ops, pipeline
+    from balf_amd.model import get_model
+    from balf_amd.utils import synth
+
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, dense f32 MFMA
 PEAK_FP16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA (the hardware's peak: the split path spends 3 products per MAC)
@@ -177,6 +183,107 @@ def index_match(gpu, cpu_probs, cpu_dets, h, w, k, top, left):
             "prob_max_abs_err": err, "tolerance": 1e-4}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start N fresh ranks of this script (one per GPU) and relay
+    rank 0's JSON line.  This parent never touches the GPU (no torch.cuda call, no HIP call): a process that has
+    initialised the GPU must not be replaced or forked on this pool, so the ranks are plain child processes with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set.
+    Returns the exit status: 0 only if every rank exited 0 and rank 0 printed its line."""
+    import subprocess
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0.setdefault("MASTER_PORT", str(_free_port()))
+    env0["WORLD_SIZE"] = env0["LOCAL_WORLD_SIZE"] = str(n)
+    env0["BALF_BENCH_LAUNCHED"] = "1"
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    # rank 0's stdout carries the one JSON line: a thread drains it while this one watches the ranks; the first rank that
+    # fails takes the others down with it (a rank waiting in a rendezvous for a dead peer would otherwise sit out its timeout)
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    status, live = 0, dict(enumerate(procs))
+    while live:
+        for r, p in list(live.items()):
+            rc = p.poll()
+            if rc is None:
+                continue
+            del live[r]
+            if rc != 0:
+                print(f"[bench] rank {r} exited with status {rc}", file=sys.stderr)
+                if status == 0:
+                    status = rc if rc > 0 else 1
+                    for q in live.values():
+                        q.terminate()         # these exact children, nothing matched by pattern
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    line0 = (buf[0] if buf else b"").decode()
+    lines = [ln for ln in line0.splitlines() if ln.strip()]
+    if status == 0 and len(lines) != 1:
+        print(f"[bench] rank 0 printed {len(lines)} lines instead of one JSON line", file=sys.stderr)
+        status = 1
+    if status == 0:
+        sys.stdout.write(lines[0] + "\n")
+        sys.stdout.flush()
+    return status
+
+
+def stub_main(args, json_fd):
+    """--stub-step: the launch / rendezvous / collective / report plumbing of this script with the GPU taken out — a gloo
+    group on the CPU, fixed fake keypoint slabs as the step's result.  It exists for tests/test_bench_launcher.py (the
+    N > 1 path of bench.py on a box without GPUs) and is marked as such in its line; it measures nothing."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, k = args.batch_per_gpu, args.topk
+    g = torch.Generator().manual_seed(77 + rank)
+    idx = torch.randint(0, 1 << 20, (b, k), generator=g, dtype=torch.int32)
+    score, count = torch.rand((b, k), generator=g), torch.full((b,), k, dtype=torch.int32)
+
+    def step():
+        return pipeline.allgather_keypoints(idx, score, count, force=True)
+    for _ in range(args.warmup):
+        out = step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, -dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max, dt_min = float(t[0]), -float(t[1])
+    assert out[0].shape == (world * b, k) and torch.equal(out[0][rank * b:(rank + 1) * b], idx)
+    if rank == 0:
+        res = {"metric": "bench.py launcher plumbing (stub step: no detector, no GPU)", "stub": True,
+               "value": world * b * args.steps / dt_max, "unit": "images/s", "n_gpus": world,
+               "rccl_ranks": dist.get_world_size(), "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "none", "data": "synthetic",
+               "per_rank_images_per_s": {"min": b * args.steps / dt_max, "max": b * args.steps / dt_min},
+               "config": {"workload": f"stub: {b} x {k} fake keypoints per rank, all-gather only", "global_batch": b * world,
+                          "parallelism": f"dp{world}"},
+               "launched_by": "bench.py" if os.environ.get("BALF_BENCH_LAUNCHED") else "external launcher"}
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,7 +300,13 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-single-rank-collective", action="store_true",
                     help="at N = 1 skip the single-rank RCCL group (then the step has no collective)")
+    ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)   # launcher test on the CPU (gloo), see stub_main
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # the driver's plain `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    _import_product()
 
     # stdout carries exactly ONE line, the JSON: libraries that print banners there (RCCL prints its version block when
     # the first communicator comes up) are sent to stderr for the duration of the run
@@ -204,6 +317,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # never report one GPU count under another's name: the scaling run divides by --gpus
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (plain "
+                         f"`python bench.py --gpus {args.gpus}` does it itself) or pass --gpus {world}")
+    if args.stub_step:
+        return stub_main(args, json_fd)
+    n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if n_dev < max(world, local_rank + 1):
+        raise SystemExit(f"[bench] rank {rank}: {n_dev} GPU(s) visible, {world} ranks asked for: refusing to report "
+                         f"n_gpus={world} from fewer devices")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: balf_amd has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -225,9 +348,6 @@ def main():
             have_group = True
         except Exception as e:          # noqa: BLE001 -- report and go on without it
             collective_note = f"none (single-rank RCCL group failed: {type(e).__name__}: {e})"[:200]
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
-
     h, w, k, b = args.height, args.width, args.topk, args.batch_per_gpu
     hp, wp, top, left = arch.padded_hw(h, w)
     state = synth.synthetic_state_dict(20240)
@@ -274,11 +394,15 @@ def main():
         fence()
         dt_ = time.perf_counter() - t0
         prof_ = ops.profile_end()
+        rank_dt[:] = [dt_, dt_]
         if have_group and world > 1:
-            tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([dt_, -dt_], dtype=torch.float64, device=dev)     # max and (negated) min over ranks
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt_ = float(tmax.item())
+            dt_ = float(tmax[0].item())
+            rank_dt[:] = [dt_, -float(tmax[1].item())]
         return dt_, prof_, o
+
+    rank_dt = [0.0, 0.0]                    # slowest / fastest rank's time of the last timed_run
 
     mb = max(1, min(b, 16 * 1024 * 1024 // (hp * wp)))          # images per launch (make_plan in det_common.h)
 
@@ -339,6 +463,23 @@ def main():
     counts = out[2]
     kp_per_image = float(counts.float().mean().item())
     head = summarize(args.precision, dt, prof, args.steps)
+    per_rank = {"min": b * args.steps / rank_dt[0], "max": b * args.steps / rank_dt[1]}
+
+    # the collective by itself: device time of pack + all_gather_into_tensor + unpack on this rank's slabs, events on the
+    # stream it runs on (RCCL is stream-ordered on torch's current stream)
+    allgather_us = None
+    if have_group:
+        i_, s_, c_ = out[3][0], out[3][1], out[3][2]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            pipeline.allgather_keypoints(i_, s_, c_, force=True)
+        fence()
+        e0.record()
+        for _ in range(20):
+            pipeline.allgather_keypoints(i_, s_, c_, force=True)
+        e1.record()
+        fence()
+        allgather_us = e0.elapsed_time(e1) * 1e3 / 20
     gpu_sample = tuple(t[:max(args.cpu_images, 1)].clone() for t in out[3])     # this rank's first images
 
     other = None
@@ -383,7 +524,11 @@ def main():
             "metric": "images/sec + keypoints/sec on 1080p gray (detector forward + NMS + top-K); NMS index match vs CPU ref",
             "value": ips, "unit": "images/s", "keypoints_per_s": ips * kp_per_image,
             "keypoints_per_image": kp_per_image,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "n_gpus": world, "rccl_ranks": dist.get_world_size() if have_group else 0,
+            "per_rank_images_per_s": per_rank, "allgather_device_us": allgather_us,
+            "launched_by": "bench.py" if os.environ.get("BALF_BENCH_LAUNCHED") else
+                           ("external launcher" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "direct"),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{b} images/GPU x {world} GPU, {w}x{h} gray -> [B,3,{hp},{wp}] fp32, top-{k}, "

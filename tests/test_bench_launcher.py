@@ -1,0 +1,86 @@
+"""bench.py's N > 1 launch path on a box without GPUs: `python bench.py --gpus 2` starts two fresh
+ranks itself, the parent never imports torch or the product library, rank 0 prints ONE JSON line with n_gpus 2, and
+every way of ending up with fewer devices or ranks than --gpus fails loudly instead of reporting n_gpus = 1.
+The step is the stub of bench.stub_main (gloo, fake keypoint slabs): this tests plumbing, it measures nothing."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+STUB = ["--stub-step", "--steps", "3", "--warmup", "1", "--batch-per-gpu", "4", "--topk", "16"]
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID")}
+    env.update(kw)
+    return env
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _one_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_plain_gpus2_starts_two_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + STUB, env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _one_line(r.stdout)
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["stub"] is True
+    assert res["launched_by"] == "bench.py" and res["config"]["global_batch"] == 8
+    assert res["per_rank_images_per_s"]["min"] <= res["per_rank_images_per_s"]["max"]
+
+
+def test_torchrun_form_gives_the_same_line():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2"] + STUB,
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _one_line(r.stdout)
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["launched_by"] == "external launcher"
+
+
+def test_world_size_mismatch_fails_loudly():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + STUB, env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "--gpus 2 but WORLD_SIZE=1" in r.stderr
+
+
+def test_too_few_devices_fails_loudly():
+    """the real step on this GPU-less box: every rank sees 0 devices, exits non-zero, and the launcher prints no line"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("box has >= 2 GPUs")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "refusing to report" in r.stderr
+
+
+def test_launcher_parent_does_not_load_torch_or_the_library():
+    """the parent of `--gpus N` must not touch the GPU: it may not even import torch or load libbalf_hip.so"""
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '2'] + %r\n"
+            "import subprocess\n"
+            "class P:\n"
+            "    def __init__(s, *a, **k): s.stdout = open('/dev/null', 'rb')\n"
+            "    def poll(s): return 7\n"
+            "    def terminate(s): pass\n"
+            "subprocess.Popen = P\n"
+            "try:\n"
+            "    runpy.run_path(%r, run_name='__main__')\n"
+            "except SystemExit as e:\n"
+            "    assert e.code == 7, e.code\n"
+            "assert 'torch' not in sys.modules and 'balf_amd' not in sys.modules and 'numpy' not in sys.modules\n"
+            "print('clean')\n") % (STUB, BENCH)
+    r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "clean", r.stderr[-2000:]
