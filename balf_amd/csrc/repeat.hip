@@ -295,7 +295,11 @@ __device__ __forceinline__ double ones_inner(int y, int x, int h, int w, int b) 
     return (y >= b && y < h - b && x >= b && x < w - b) ? 1.0 : 0.0;      // zero outside the image too
 }
 
+// fp contraction is OFF in this kernel and in invert3: every product and sum below is an individually rounded fp64
+// operation in source order, so that the CPU oracle (NumPy, no FMA) reproduces the 1/32-pixel rounding bit for bit and the
+// two {0,1} masks can be compared for equality.
 __global__ __launch_bounds__(256) void common_mask_kernel(MaskArgs a) {
+#pragma clang fp contract(off)
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)a.h_out * a.w_out) return;
     const int y = (int)(i / a.w_out), x = (int)(i - (long)y * a.w_out);
@@ -319,7 +323,9 @@ __global__ __launch_bounds__(256) void common_mask_kernel(MaskArgs a) {
     a.out[i] = v;
 }
 
+// closed-form 3x3 inverse (adjugate / determinant), the form OpenCV's cv::invert takes for n <= 3
 bool invert3(const double *m, double *o) {
+#pragma clang fp contract(off)
     const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
     const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
     const double det = a * A + b * B + c * C;

@@ -254,9 +254,8 @@ __device__ __forceinline__ const T *uniform_ptr(const T *p) {
     return reinterpret_cast<const T *>(((unsigned long long)hi << 32) | lo);
 }
 
-#ifndef BALF_S1_FUSE
-#define BALF_S1_FUSE 1       // 1: the block kernel stores x1 and the channel sums of the RCAB's hidden layer only; tail kernel (MODE 2)
-#endif
+// The block kernel stores x1 and the channel sums of the RCAB's hidden layer only; the tail kernel (MODE 2) recomputes the
+// RCAB branch from x1.  (The round-2 alternative that stored T and R for a pool kernel is gone.)
 #ifndef BALF_S1_KEEP_X0
 #define BALF_S1_KEEP_X0 1    // block kernel: keep x0 in registers (32; there is room since conv0 left the f16 path) instead of recomputing it: -5 %
 #endif
@@ -662,10 +661,8 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
                         x1[nt][p] += x0v[nt][p];
-                        if constexpr (BALF_S1_FUSE != 0)         // x1 itself: the tail kernel adds x0 and the scaled RCAB branch
-                            *reinterpret_cast<f4 *>(A.R + (pix0 + p * pstep) * C + 16 * nt + 4 * q) = x1[nt][p];
-                        else
-                            *reinterpret_cast<f4 *>(A.R + (pix0 + p * pstep) * C + 16 * nt + 4 * q) = x1[nt][p] + x0v[nt][p];
+                        // x1 itself: the tail kernel adds x0 and the scaled RCAB branch
+                        *reinterpret_cast<f4 *>(A.R + (pix0 + p * pstep) * C + 16 * nt + 4 * q) = x1[nt][p];
                     }
             }
             STAMP(10);  // conv0 again, residuals, R store
@@ -674,35 +671,19 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             s1_bias(m1, par + kS1pR1B, q);
             s1_linear(m1, wl + kS1R1, 2048, b);
             lrelu(m1);
-            f4 t[2][P];
-            if constexpr (BALF_S1_FUSE != 0) {
-                // conv2 is linear: its channel means follow from the means of its input, and the tail kernel
-                // (stage1_tail_kernel16) recomputes the RCAB branch from x1 -- no T tensor through HBM
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int p = 0; p < P; ++p) t[nt][p] = m1[nt][p];
-            } else {
-                s1_split(m1, b);
-                STAMP(11);  // LN + conv1 + lrelu + split
-                s1_bias(t, par + kS1pR2B, q);
-                s1_linear(t, wl + kS1R2, 2048, b);
-            }
+            // conv2 is linear: its channel means follow from the means of its input (the hidden layer m1), and the tail
+            // kernel recomputes the RCAB branch from x1 -- no T tensor through HBM
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                f4 s = t[nt][0];
-                if constexpr (BALF_S1_FUSE == 0) *reinterpret_cast<f4 *>(A.T + pix0 * C + 16 * nt + 4 * q) = t[nt][0];
+                f4 s = m1[nt][0];
 #pragma unroll
-                for (int p = 1; p < P; ++p) {
-                    if constexpr (BALF_S1_FUSE == 0) *reinterpret_cast<f4 *>(A.T + (pix0 + p * pstep) * C + 16 * nt + 4 * q) = t[nt][p];
-                    s += t[nt][p];
-                }
+                for (int p = 1; p < P; ++p) s += m1[nt][p];
                 // channel sums over the group's 64 pixels (fixed order): over the 16 lanes of the row, then lane li = 0 stores
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[r] = row_ror_add<1>(row_ror_add<2>(row_ror_add<4>(row_ror_add<8>(s[r]))));
                 if (li == 0) *reinterpret_cast<f4 *>(A.partial + (long)item * C + 16 * nt + 4 * q) = s;
             }
-            STAMP(12);  // conv2 + T store + channel sums
+            STAMP(12);  // channel sums of the hidden layer
         }
         }   // !TAIL
     }

@@ -25,16 +25,13 @@ template <int C> constexpr int cs_bt_bytes() {                                  
     return bt > bu ? bt : bu;
 }
 template <int C> constexpr bool cs_mix_in_lds() { return C >= 256; }
-#ifndef BALF_CS_FUSE_MAXC
-#define BALF_CS_FUSE_MAXC 128 // stages with C <= this: tail kernel (MODE 2) instead of the T / R round trip through the pool kernel (0: none)
-#endif
 // Fused tail (as in stage 1, stage1_f16.h): the block kernel stores x1 and the channel sums of the RCAB's hidden layer;
 // MODE 2 of the kernel below recomputes x0 and the RCAB branch from x1, scales, pools and writes the next stage's input.
 // Measured per stage (ms per 8 images at 1088x1920, block + pool -> block + tail): C = 64 1.98 -> 1.75; C = 128 1.32 -> 1.28
 // (there the tail streams conv0 + conv1 + conv2 -- 164 KB per token group -- from L2, which is what bounds it: 0.23 ms
 // with the weight tiles served from L1 in an ablation build, 0.35 ms as it is, against 0.24 ms of the pool kernel).
 // Not at C = 256: there the consumer is the head kernel.
-template <int C> constexpr bool cs_fused() { return C <= BALF_CS_FUSE_MAXC && C <= 128; }                    // C <= 128: more workgroups per CU instead
+template <int C> constexpr bool cs_fused() { return C <= 128; }
 template <int C> constexpr int cs_tail_lds_bytes() {      // tail: B fragments, statistics, the stage input (no token tiles)
     return cs_bx_bytes<C>() + cs_waves<C>() * 4 * 16 * 8 + (C / 64) * 4 * 2048;
 }

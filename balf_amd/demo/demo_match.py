@@ -86,7 +86,9 @@ def detect(args, im, detector, device):
     """demo_match.py:21-57: image [H,W,3] uint8 -> keypoints [n,3] = (x, y, 1), strongest first."""
     pts = _detect_gpu(args, im, detector, device)
     if pts.shape[0] == 0:
-        return np.zeros([0, 3])
+        # the reference returns a PAIR here (demo_match.py:51-52) although every other path returns one array: mirrored,
+        # pinned by tests/golden/callers.npz (d_conf_high)
+        return np.zeros([0, 3]), np.zeros([0, 1])
     return pts.double().cpu().numpy()
 
 

@@ -269,6 +269,30 @@ def soft_argmax_refine(heatmap: np.ndarray, idx: np.ndarray, patch: int) -> np.n
     return out
 
 
+def demo_detect(sd, im_rgb_u8: np.ndarray, border_size=15, nms_size=15, num_features=2048, conf_thresh=0.001,
+                sub_pixel=True, patch_size=4, order_coord="xysr", prob_pad: np.ndarray = None):
+    """``demo_match.detect`` (demo/demo_match.py:21-57): /255 -> pad -> forward -> crop -> remove_borders ->
+    get_points_direct_from_score_map (threshold, greedy NMS, optional sub-pixel) -> strongest num_features rows (x, y, 1).
+    ``prob_pad`` replaces the forward (identical-input checks).  The reference returns a PAIR of empty arrays when nothing
+    passes (:51-52); so does this."""
+    h, w = im_rgb_u8.shape[:2]
+    if prob_pad is None:
+        pad = mod_padding_symmetric(make_shape_even(im_rgb_u8 / 255.), 64)
+        x = torch.tensor(pad, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0)
+        with torch.no_grad():
+            prob_pad = detector_forward(sd, x)["prob"][0].numpy()
+    top, left = crop_offsets(h, w, *prob_pad.shape)
+    heat = remove_borders(prob_pad[top:top + h, left:left + w], border_size)
+    idx, sc = greedy_nms(heat, conf_thresh, nms_size)
+    if idx.size == 0:
+        return np.zeros([0, 3]), np.zeros([0, 1])
+    xy = soft_argmax_refine(heat, idx, patch_size) if sub_pixel else np.stack([idx % w, idx // w], axis=1).astype(np.float64)
+    xy = xy[:num_features]
+    if order_coord == "yxsr":
+        xy = xy[:, ::-1]
+    return np.concatenate([xy, np.ones((xy.shape[0], 1))], axis=1)
+
+
 # ----------------------------------------------------------------------------------------
 # demo descriptor / matching path (SURVEY.md 8 f3)
 # ----------------------------------------------------------------------------------------
@@ -480,13 +504,27 @@ def compute_repeatability_with_maximum_filter(src_scores, dst_scores, homography
 # ----------------------------------------------------------------------------------------
 # common-region masks of the evaluation (geometry_tools.py:7-26)
 # ----------------------------------------------------------------------------------------
+def invert3(m: np.ndarray) -> np.ndarray:
+    """Closed-form 3x3 inverse (adjugate / determinant) in individually rounded fp64 operations -- the form OpenCV's
+    cv::invert takes for n <= 3, and operation for operation what balf_common_region_masks computes on the host."""
+    a, b, c, d, e, f, g, h, i = (float(v) for v in np.asarray(m, dtype=np.float64).reshape(9))
+    A, B, C = e * i - f * h, -(d * i - f * g), d * h - e * g
+    det = a * A + b * B + c * C
+    if det == 0.0:
+        raise np.linalg.LinAlgError("singular homography")
+    r = 1.0 / det
+    return np.array([[A * r, -(b * i - c * h) * r, (b * f - c * e) * r],
+                     [B * r, (a * i - c * g) * r, -(a * f - c * d) * r],
+                     [C * r, -(a * h - b * g) * r, (a * e - b * d) * r]], dtype=np.float64)
+
+
 def warp_perspective_linear(src: np.ndarray, m: np.ndarray, dsize) -> np.ndarray:
     """cv2.warpPerspective(src, m, dsize) with its default flags (bilinear, BORDER_CONSTANT 0), restated from OpenCV's
     algorithm for a float64 image: dst(x, y) = src(M^-1 (x, y, 1)); source coordinates rounded to 1/32 pixel
     (INTER_TAB_SIZE 32, round half to even).  cv2 is not installed in the build container: this restatement is
     PARITY UNPINNED against cv2 itself."""
     w, h = int(dsize[0]), int(dsize[1])
-    mi = np.linalg.inv(np.asarray(m, dtype=np.float64))
+    mi = invert3(m)
     ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
     wv = mi[2, 0] * xs + mi[2, 1] * ys + mi[2, 2]
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -509,7 +547,7 @@ def warp_perspective_linear(src: np.ndarray, m: np.ndarray, dsize) -> np.ndarray
 def create_common_region_masks(h_dst_2_src, shape_src, shape_dst):
     """geometry_tools.py:7-26 with ``warp_perspective_linear`` in the place of cv2.warpPerspective."""
     h_dst_2_src = np.asarray(h_dst_2_src, dtype=np.float64)
-    inv_h = np.linalg.inv(h_dst_2_src)
+    inv_h = invert3(h_dst_2_src)                     # (the reference: np.linalg.inv; equal up to the last bits)
     inv_h = inv_h / inv_h[2, 2]
     ones_dst = remove_borders(np.ones((shape_dst[0], shape_dst[1])), 15)
     mask_src = warp_perspective_linear(ones_dst, h_dst_2_src, (shape_src[1], shape_src[0]))

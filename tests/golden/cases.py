@@ -17,11 +17,27 @@ TAP_CASE = "b2_64x64"
 # name -> (h, w, K, synthetic image index)  un-padded image sizes, run through pad/crop
 FORWARD_CFG = {
     "vga": (480, 640, 1000, 0),
+    "720p": (720, 1280, 2000, 1),          # BASELINE configs[2]
+    "1080p": (1080, 1920, 2000, 2),        # BASELINE configs[3]/[4]: fh = 136, fw = 240 in the stage-1 grid branch
 }
 
 
 def CFG_ROWS(hp):
     return np.array([0, 1, hp // 3, hp // 2, hp - 2, hp - 1])
+
+
+def cfg_mix(prob):
+    """One pixel per 8x8 cell at a cell-dependent offset, so that all 64 head channels are sampled (prob[::8, ::8] only
+    ever sees channel 0)."""
+    hc, wc = prob.shape[0] // 8, prob.shape[1] // 8
+    i, j = np.mgrid[0:hc, 0:wc]
+    return prob[8 * i + (3 * i + 5 * j) % 8, 8 * j + (i + 2 * j) % 8].copy()
+
+
+def cfg_cellsum(prob):
+    """float64 sum of each 8x8 cell (= 1 - dustbin probability): every pixel of the map enters."""
+    hc, wc = prob.shape[0] // 8, prob.shape[1] // 8
+    return prob.astype(np.float64).reshape(hc, 8, wc, 8).sum(axis=(1, 3))
 
 
 def forward_input(b, h, w, seed):
@@ -170,3 +186,29 @@ def eval_inputs(spec):
     mask_dst = np.zeros((h, w)); mask_dst[22:h - 18, 20:w - 30] = 1.0
     del hinv
     return src.astype(np.float32), dst.astype(np.float32), mask_src, mask_dst
+
+
+# the demo's caller (demo/demo_match.py:21-57 `detect`), executed from the reference's source: name -> (h, w, image index,
+# overrides of config.parse_test_config's defaults).  Inputs are uint8 RGB images as load_im returns them.
+DETECT_ARGS = dict(border_size=15, nms_size=15, num_features=2048, s_mult=60, order_coord="xysr",
+                   heatmap_confidence_threshold=0.001, sub_pixel=True, patch_size=4)
+DETECT_CASES = {
+    "d_240x320":     (240, 320, 40, {}),
+    "d_nosub":       (240, 320, 40, dict(sub_pixel=False)),
+    "d_odd_199x301": (199, 301, 41, dict(sub_pixel=False)),
+    "d_few_yx":      (192, 256, 42, dict(sub_pixel=False, num_features=100, order_coord="yxsr")),
+    "d_conf_high":   (192, 256, 42, dict(sub_pixel=False, heatmap_confidence_threshold=0.9999)),     # nothing passes
+}
+
+
+def detect_input(h, w, index):
+    from balf_amd.utils import synth
+    return np.stack([synth.synthetic_gray_u8(h, w, index + 7 * c, blur=5) for c in range(3)], axis=-1)
+
+
+# the benchmark's caller (balf/utils/train_utils.py:416-454 `extract_detections`) beyond the FORWARD_CFG sizes:
+# name -> (h, w, K, image index, border, nms)
+EXTRACT_CASES = {
+    "e_100x130": (100, 130, 50, 50, 15, 15),
+    "e_odd_201x333_nms5": (201, 333, 300, 51, 4, 5),
+}

@@ -44,13 +44,23 @@ from tests.golden import cases                              # noqa: E402
 torch.set_num_threads(8)
 
 
-def ref_functions(path, names, extra=None):
+def ref_functions(path, names, extra=None, drop_assign=None):
     """Compile the named top-level functions of a reference source file, unchanged, into a fresh namespace (the
-    module itself cannot be imported here: it pulls in packages that are not installed)."""
+    module itself cannot be imported here: it pulls in packages that are not installed).  `drop_assign` = a variable
+    name whose (single) plain assignment statement is left out -- used for ONE statement of the reference that raises on
+    the reference's own model (see ref_extract_detections)."""
     import ast
     tree = ast.parse(open(path).read())
     keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
     assert sorted(n.name for n in keep) == sorted(names)
+    if drop_assign:
+        hit = 0
+        for fn in keep:
+            body = [st for st in fn.body if not (isinstance(st, ast.Assign) and len(st.targets) == 1 and
+                                                 isinstance(st.targets[0], ast.Name) and st.targets[0].id == drop_assign)]
+            hit += len(fn.body) - len(body)
+            fn.body = body
+        assert hit == 1, hit
     ns = {"np": np}
     ns.update(extra or {})
     exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
@@ -66,20 +76,72 @@ def ref_model(seed):
     return m, cfg
 
 
-def ref_detect(score_pad, h, w, border, nms_size, k):
-    """The glue of train_utils.extract_detections:437-452 around the reference's own functions."""
-    hp, wp = score_pad.shape
-    he, we = h + (h & 1), w + (w & 1)
-    hs, ws = hp // 2 - he // 2, wp // 2 - we // 2
-    score = score_pad[hs:hs + h, ws:ws + w]
-    nms = RT.apply_nms(RT.remove_borders(score, borders=border), nms_size)
-    pts = RT.get_point_coordinates(nms, num_points=k, order_coord="xysr")
+def ref_extract_detections(unmodified=False):
+    """train_utils.extract_detections (balf/utils/train_utils.py:416-454) compiled from the reference's source, with the
+    modules it calls into (dataset_utils, geometry_tools, repeatability_tools -- none importable here) supplied the same way.
+
+    As published the function RAISES on the reference's own model: :444 indexes `output['prob']` -- which DetectorHead
+    squeezes to [B,H,W] (decoder.py:27) -- with four subscripts (IndexError).  That statement only feeds the second return
+    value; `unmodified=False` leaves that one assignment out (the name then resolves to a module-level None) and executes
+    everything the keypoints depend on exactly as written."""
+    import types
+    from scipy.ndimage import maximum_filter
+    du = ref_functions("/root/reference/balf/datasets/dataset_utils.py", ["make_shape_even", "mod_padding_symmetric"])
+    gt = ref_functions("/root/reference/balf/benchmark_test/geometry_tools.py",
+                       ["remove_borders", "get_point_coordinates", "find_index_higher_scores"])
+    rt = ref_functions("/root/reference/balf/benchmark_test/repeatability_tools.py", ["apply_nms"],
+                       {"maximum_filter": maximum_filter})
+    ns = {"torch": torch, "dataset_utils": types.SimpleNamespace(**du), "geometry_tools": types.SimpleNamespace(**gt),
+          "repeatability_tools": types.SimpleNamespace(**rt), "score_map_batch": None}
+    return ref_functions("/root/reference/balf/utils/train_utils.py", ["extract_detections"], ns,
+                         drop_assign=None if unmodified else "score_map_batch")["extract_detections"]
+
+
+def ref_demo_detect():
+    """demo_match.detect (demo/demo_match.py:21-57) compiled from the reference's source; its one module dependency,
+    balf.utils.test_utils, is the importable reference module itself."""
+    return ref_functions("/root/reference/demo/demo_match.py", ["detect"], {"torch": torch, "test_utils": RT})["detect"]
+
+
+def pts_to_idx(pts, w):
+    """rows [x, y, 1, score] -> (flat indices sorted ascending, their scores)"""
     if pts.size == 0:
         return np.zeros(0, np.int64), np.zeros(0, np.float32)
     idx = (pts[:, 1].astype(np.int64) * w + pts[:, 0].astype(np.int64))
     sc = pts[:, 3].astype(np.float32)
     o = np.argsort(idx)
     return idx[o], sc[o]
+
+
+def make_torchgeometry_stub():
+    """A module object standing in for torchgeometry with a restatement of its one call on this path (see main)."""
+    import types
+
+    class SpatialSoftArgmax2d(torch.nn.Module):
+        def __init__(self, normalized_coordinates=True):
+            super().__init__()
+            self.normalized_coordinates = normalized_coordinates
+            self.eps = 1e-6
+
+        def forward(self, input):
+            b, c, hh, ww = input.shape
+            x = input.view(b, c, -1)
+            exp_x = torch.exp(x - torch.max(x, dim=-1, keepdim=True)[0])
+            exp_x_sum = 1.0 / (exp_x.sum(dim=-1, keepdim=True) + self.eps)
+            if self.normalized_coordinates:
+                xs, ys = torch.linspace(-1, 1, ww), torch.linspace(-1, 1, hh)
+            else:
+                xs, ys = torch.linspace(0, ww - 1, ww), torch.linspace(0, hh - 1, hh)
+            pos_y, pos_x = torch.meshgrid(ys, xs, indexing="ij")
+            pos_x, pos_y = pos_x.reshape(-1).to(input.dtype), pos_y.reshape(-1).to(input.dtype)
+            expected_y = torch.sum((pos_y * exp_x) * exp_x_sum, dim=-1, keepdim=True)
+            expected_x = torch.sum((pos_x * exp_x) * exp_x_sum, dim=-1, keepdim=True)
+            return torch.cat([expected_x, expected_y], dim=-1).view(b, c, 2)
+
+    tgm = types.ModuleType("torchgeometry")
+    tgm.contrib = types.ModuleType("torchgeometry.contrib")
+    tgm.contrib.SpatialSoftArgmax2d = SpatialSoftArgmax2d
+    return tgm
 
 
 def main():
@@ -106,19 +168,57 @@ def main():
     np.savez_compressed(os.path.join(HERE, "forward_small.npz"), **fw)
 
     # ---------------- forward at a config size (strided samples + detections) ----------------
+    # The score map is taken from inside the reference's own caller: extract_detections runs pad -> model -> crop ->
+    # remove_borders -> apply_nms -> get_point_coordinates -> sort itself, a forward hook on the model records the padded
+    # score map it produced on the way (one forward per size: 1.3 / 3 / 7 s).
+    extract = ref_extract_detections()
     fc = {}
+    seen = {}
+    hook = m.register_forward_hook(lambda mod, i, o: seen.__setitem__("prob", o["prob"][0].detach().numpy().copy()))
     for name, (h, w, k, img_index) in cases.FORWARD_CFG.items():
         img = synth.gray_to_rgb_norm(synth.synthetic_gray_u8(h, w, img_index))
-        pad = RT.mod_padding_symmetric(RT.make_shape_even(img), factor=64)
-        x = torch.tensor(pad, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0)
-        with torch.inference_mode():
-            prob = m(x)["prob"][0].numpy()
+        pts, none = extract(img, m, "cpu", nms_size=15, num_points=k, border_size=15)
+        assert none is None and pts.shape == (k, 4)
+        prob = seen.pop("prob")
         fc[name + ".prob_s8"] = prob[::8, ::8].copy()
         fc[name + ".prob_rows"] = prob[cases.CFG_ROWS(prob.shape[0])].copy()
-        idx, sc = ref_detect(prob, h, w, 15, 15, k)
+        idx, sc = pts_to_idx(pts, w)
         fc[name + ".idx"] = idx.astype(np.int32)
         fc[name + ".score"] = sc
+        if name != "vga":                   # (the vga entry keeps its round-1 key set)
+            fc[name + ".prob_mix"] = cases.cfg_mix(prob)
+            fc[name + ".prob_cellsum"] = cases.cfg_cellsum(prob)
+            fc[name + ".pts"] = pts         # the caller's own return value: rows [x, y, 1.0, score] float64, score descending
     np.savez_compressed(os.path.join(HERE, "forward_cfg.npz"), **fc)
+
+    # ---------------- the two callers, executed from the reference's source ----------------
+    import types
+    ck2 = {}
+    for name, (h, w, k, img_index, border, nms) in cases.EXTRACT_CASES.items():
+        img = synth.gray_to_rgb_norm(synth.synthetic_gray_u8(h, w, img_index))
+        pts, _ = extract(img, m, "cpu", nms_size=nms, num_points=k, border_size=border)
+        ck2[name + ".pts"] = pts
+        ck2[name + ".prob"] = seen.pop("prob")
+    hook.remove()
+    try:
+        ref_extract_detections(unmodified=True)(synth.gray_to_rgb_norm(synth.synthetic_gray_u8(64, 64, 0)), m, "cpu")
+        unmodified = "ok"
+    except IndexError as e:
+        unmodified = f"IndexError: {e}"
+    detect = ref_demo_detect()
+    # sub_pixel=True reaches torchgeometry (absent): the restatement of its one call, defined below for subpixel.npz, is
+    # installed for these cases too -- same caveat: the reference's side is pinned, the third-party call is not
+    tgm_stub = make_torchgeometry_stub()
+    sys.modules["torchgeometry"], sys.modules["torchgeometry.contrib"] = tgm_stub, tgm_stub.contrib
+    for name, (h, w, img_index, over) in cases.DETECT_CASES.items():
+        args = types.SimpleNamespace(**dict(cases.DETECT_ARGS, **over))
+        res = detect(args, cases.detect_input(h, w, img_index), m, "cpu")
+        if isinstance(res, tuple):          # the empty case returns a PAIR (np.zeros([0,3]), np.zeros([0,1])), demo_match.py:51-52
+            ck2[name + ".empty_pair_shapes"] = np.asarray([r.shape for r in res])
+        else:
+            ck2[name + ".pts"] = np.asarray(res, dtype=np.float64)
+    del sys.modules["torchgeometry"], sys.modules["torchgeometry.contrib"]
+    np.savez_compressed(os.path.join(HERE, "callers.npz"), **ck2)
 
     # ---------------- NMS / top-K on synthetic score maps ----------------
     nk = {}
@@ -165,32 +265,7 @@ def main():
     # (torchgeometry 0.1.2, contrib/spatial_soft_argmax2d.py: soft-max over the flattened patch with the max-subtraction
     # trick and eps = 1e-6 in the normaliser, expectation of the pixel grid, output (x, y)).  So these vectors pin the
     # reference's side of the sub-pixel path; the third-party call itself stays unpinned.
-    import types
-
-    class SpatialSoftArgmax2d(torch.nn.Module):
-        def __init__(self, normalized_coordinates=True):
-            super().__init__()
-            self.normalized_coordinates = normalized_coordinates
-            self.eps = 1e-6
-
-        def forward(self, input):
-            b, c, hh, ww = input.shape
-            x = input.view(b, c, -1)
-            exp_x = torch.exp(x - torch.max(x, dim=-1, keepdim=True)[0])
-            exp_x_sum = 1.0 / (exp_x.sum(dim=-1, keepdim=True) + self.eps)
-            if self.normalized_coordinates:
-                xs, ys = torch.linspace(-1, 1, ww), torch.linspace(-1, 1, hh)
-            else:
-                xs, ys = torch.linspace(0, ww - 1, ww), torch.linspace(0, hh - 1, hh)
-            pos_y, pos_x = torch.meshgrid(ys, xs, indexing="ij")
-            pos_x, pos_y = pos_x.reshape(-1).to(input.dtype), pos_y.reshape(-1).to(input.dtype)
-            expected_y = torch.sum((pos_y * exp_x) * exp_x_sum, dim=-1, keepdim=True)
-            expected_x = torch.sum((pos_x * exp_x) * exp_x_sum, dim=-1, keepdim=True)
-            return torch.cat([expected_x, expected_y], dim=-1).view(b, c, 2)
-
-    tgm = types.ModuleType("torchgeometry")
-    tgm.contrib = types.ModuleType("torchgeometry.contrib")
-    tgm.contrib.SpatialSoftArgmax2d = SpatialSoftArgmax2d
+    tgm = make_torchgeometry_stub()
     sys.modules["torchgeometry"], sys.modules["torchgeometry.contrib"] = tgm, tgm.contrib
     sk = {}
     for name, patch in cases.SUBPIXEL_CASES:
@@ -306,6 +381,7 @@ def main():
             geo["loader"]["missing_file"] = "ok"
         except FileNotFoundError:
             geo["loader"]["missing_file"] = "FileNotFoundError"
+    geo["extract_detections_unmodified"] = unmodified        # what train_utils.extract_detections does as published
     geo["versions"] = {"torch": torch.__version__, "numpy": np.__version__}
     with open(os.path.join(HERE, "geometry.json"), "w") as f:
         json.dump(geo, f, indent=1)

@@ -75,6 +75,68 @@ def test_forward_cfg_vga(sd):
     assert pts.shape == (k, 4) and np.all(np.diff(pts[:, 3]) <= 0) and np.all(pts[:, 2] == 1.0)
 
 
+@pytest.mark.parametrize("name", ["720p", "1080p"])
+def test_forward_cfg_headline_sizes(sd, name):
+    """The oracle against the REFERENCE at the headline geometry (1088x1920: fh = 136, fw = 240 in the stage-1 grid
+    branch), fixtures recorded from inside the reference's own extract_detections (make_golden.py)."""
+    f = np.load(os.path.join(G, "forward_cfg.npz"))
+    h, w, k, img_index = cases.FORWARD_CFG[name]
+    img = synth.gray_to_rgb_norm(synth.synthetic_gray_u8(h, w, img_index))
+    pts, prob = O.extract_detections(sd, img, nms_size=15, num_points=k, border_size=15)
+    assert np.abs(prob[::8, ::8] - f[name + ".prob_s8"]).max() < 2e-6
+    assert np.abs(prob[cases.CFG_ROWS(prob.shape[0])] - f[name + ".prob_rows"]).max() < 2e-6
+    assert np.abs(cases.cfg_mix(prob) - f[name + ".prob_mix"]).max() < 2e-6
+    assert np.abs(cases.cfg_cellsum(prob) - f[name + ".prob_cellsum"]).max() < 2e-5
+    got = np.sort((pts[:, 1] * w + pts[:, 0]).astype(np.int64))
+    overlap = np.intersect1d(got, f[name + ".idx"].astype(np.int64)).size / k
+    assert overlap >= 0.99, overlap
+    ref = f[name + ".pts"]
+    assert ref.shape == pts.shape == (k, 4) and np.all(np.diff(ref[:, 3]) <= 0)
+
+
+@pytest.mark.parametrize("name", list(cases.EXTRACT_CASES))
+def test_extract_detections_identical_input(name):
+    """train_utils.extract_detections run from the reference's source: on the very score map the reference's model
+    produced, the oracle's crop / border / NMS / top-K gives the reference's points exactly (same set, same score bits)."""
+    c = np.load(os.path.join(G, "callers.npz"))
+    h, w, k, _, border, nms = cases.EXTRACT_CASES[name]
+    idx, sc = O.detect_from_prob(c[name + ".prob"], h, w, border, nms, k)
+    ref = c[name + ".pts"]
+    ri = (ref[:, 1] * w + ref[:, 0]).astype(np.int64)
+    o = np.lexsort((ri, -ref[:, 3]))
+    assert np.array_equal(idx, ri[o]) and np.array_equal(sc.astype(np.float64), ref[o, 3])
+    assert np.all(ref[:, 2] == 1.0) and np.all(np.diff(ref[:, 3]) <= 0)
+
+
+def test_reference_extract_detections_raises_as_published():
+    """Recorded fact: the published function indexes the 3-D `prob` with four subscripts (train_utils.py:444)."""
+    geo = json.load(open(os.path.join(G, "geometry.json")))
+    assert geo["extract_detections_unmodified"].startswith("IndexError")
+
+
+@pytest.mark.parametrize("name", list(cases.DETECT_CASES))
+def test_demo_detect_cases(sd, name):
+    """demo_match.detect run from the reference's source against the oracle's restatement, end to end from the uint8
+    image.  The oracle's score map differs from the reference's by fp32 rounding (1e-7), so integer pixel positions are
+    compared as sets with a near-tie allowance and sub-pixel coordinates within 1e-3 px."""
+    c = np.load(os.path.join(G, "callers.npz"))
+    h, w, img_index, over = cases.DETECT_CASES[name]
+    a = dict(cases.DETECT_ARGS, **over)
+    res = O.demo_detect(sd, cases.detect_input(h, w, img_index), a["border_size"], a["nms_size"], a["num_features"],
+                        a["heatmap_confidence_threshold"], a["sub_pixel"], a["patch_size"], a["order_coord"])
+    if name + ".empty_pair_shapes" in c.files:
+        assert isinstance(res, tuple) and [list(r.shape) for r in res] == c[name + ".empty_pair_shapes"].tolist()
+        return
+    ref = c[name + ".pts"]
+    assert res.shape == ref.shape and np.all(res[:, 2] == 1.0)
+    if a["sub_pixel"]:
+        assert np.abs(res - ref).max() < 1e-3
+    else:
+        same = (res == ref).all(axis=1).mean()
+        assert same >= 0.98, same
+        assert set(map(tuple, res)) == set(map(tuple, ref)) or same >= 0.98
+
+
 @pytest.mark.parametrize("name", list(cases.NMS_CASES))
 def test_nms_topk_cases(name):
     f = np.load(os.path.join(G, "nms_topk.npz"))

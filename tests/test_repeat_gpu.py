@@ -82,19 +82,21 @@ def test_evaluation_glue_matches_reference_golden():
     ((480, 640), (400, 600), [[0.93, -0.11, 31.0], [0.08, 1.04, -12.5], [1.2e-4, -6.0e-5, 1.0]]),
     ((200, 260), (300, 280), [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]),
     ((120, 160), (120, 160), [[0.5, 0.0, 200.0], [0.0, 0.5, 200.0], [0.0, 0.0, 1.0]]),       # no overlap at all
+    ((480, 640), (480, 640), [[1.0, 0.0, 7.03125], [0.0, 1.0, -3.515625], [0.0, 0.0, 1.0]]),  # every coordinate ON a 1/32-px tie
+    ((1080, 1920), (1080, 1920), [[0.98, 0.03, 11.0], [-0.02, 1.01, 5.0], [2.0e-5, -1.0e-5, 1.0]]),
 ])
 def test_common_region_masks_vs_oracle(shape_src, shape_dst, hm):
     """create_common_region_masks (geometry_tools.py:7-26).  The reference computes the masks with cv2.warpPerspective,
     which is not installed here: the HIP kernel and the oracle both restate OpenCV's algorithm (parity with cv2 itself
-    UNPINNED); they must agree everywhere except where a source coordinate falls within rounding of a 1/32-pixel tie."""
+    UNPINNED) in the same individually rounded fp64 operations (closed-form inverse, no FMA contraction), so the two {0,1}
+    masks must be EQUAL, 1/32-pixel ties included."""
     hm = np.asarray(hm, dtype=np.float64)
     ms, md = geometry_tools.create_common_region_masks(hm, shape_src, shape_dst)
     rs, rd = oracle.create_common_region_masks(hm, shape_src, shape_dst)
     assert ms.shape == tuple(shape_src) and md.shape == tuple(shape_dst) and ms.dtype == np.float64
     assert set(np.unique(ms)) <= {0.0, 1.0} and set(np.unique(md)) <= {0.0, 1.0}
     assert ms[:15].sum() == 0 and ms[:, :15].sum() == 0 and md[-15:].sum() == 0 and md[:, -15:].sum() == 0
-    for a, b in ((ms, rs), (md, rd)):
-        assert (a != b).sum() <= 4, int((a != b).sum())              # differently rounded matrix inverses at a tie
+    assert np.array_equal(ms, rs) and np.array_equal(md, rd)
 
 
 def test_common_region_masks_identity_is_the_inner_frame():
