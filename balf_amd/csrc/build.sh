@@ -19,4 +19,7 @@ for f in *.hip; do
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC obj/*.o -o ../libbalf_hip.so
+# the hand-counted waits of stage1_f16.h are checked against the built code (tests/test_build_invariants.py); the compiler that
+# produced it is recorded next to the library so that a toolchain change is visible
+$HIPCC --version | head -2 > ../libbalf_hip.toolchain.txt
 echo "built $(cd .. && pwd)/libbalf_hip.so"

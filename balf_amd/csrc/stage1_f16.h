@@ -389,20 +389,41 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     // float input, asm loads (not counted by the compiler): the image's planes at a scalar base, the lane's plane and pixel
     // offset in a VGPR.  Lanes q = 3 are masked off and keep the zeros `raw` starts with.
     const unsigned qoff = (unsigned)(cq * hw) * 4u;
-    auto issue_raw = [&](const Geo &g, unsigned (&raw)[P], f4 &rawv) {
+    // The prefetched pixels land in registers of their own (nraw / nrawv: zero, then the load -- masked-off lanes q = 3
+    // keep the zero), and ONE statement waits for them and copies them into the registers the group computes from
+    // (BALF_S1_TAKE_*: the copies sit behind the s_waitcnt inside the statement).  Round 2 loaded into the compute
+    // variable's own register ("+v") and waited in a second statement whose operand was tied to the same variable: the
+    // variable is live across the loop, so hipcc had to copy the load's destination into the loop-carried register IN
+    // FRONT of the wait, a whole iteration after the load -- correct only as long as a load never takes longer than an
+    // iteration (tools/vmcnt_audit.py; the check is now part of tests/test_build_invariants.py).
+    auto issue_raw = [&](const Geo &g, unsigned (&nraw)[P], f4 &nrawv) {
         const unsigned voff = (unsigned)(g.y * W + g.x0) * 4u + qoff;
         const float *xb = uniform_ptr(A.X + (long)g.n * 3 * (long)hw);
+#pragma unroll
+        for (int p = 0; p < P; ++p) { nraw[p] = 0u; nrawv[p] = 0.0f; }
         if (q < 3) {
             if constexpr (BM == 1) {
-                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(rawv) : "v"(voff), "s"(xb) : "memory");
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(nrawv) : "v"(voff), "s"(xb) : "memory");
             } else {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const unsigned vp = voff + (unsigned)(p * pstep) * 4u;
-                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(raw[p]) : "v"(vp), "s"(xb) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(nraw[p]) : "v"(vp), "s"(xb) : "memory");
                 }
             }
         }
+    };
+    // wait (WAIT = the s_waitcnt text), then raw <- nraw.  "+v" on raw: the copies write registers that hold the previous
+    // group's pixels, live VALU-visible values -- never a register an MFMA in flight still reads (split16.h).
+    auto take_raw = [&](unsigned (&raw)[P], f4 &rawv, const unsigned (&nraw)[P], const f4 &nrawv) {
+        if constexpr (BM == 1)
+            asm volatile(BALF_S1_WAIT_IN "\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                         : "+v"(rawv[0]), "+v"(rawv[1]), "+v"(rawv[2]), "+v"(rawv[3])
+                         : "v"(nrawv[0]), "v"(nrawv[1]), "v"(nrawv[2]), "v"(nrawv[3]) : "memory");
+        else
+            asm volatile(BALF_S1_WAIT_IN "\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                         : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3])
+                         : "v"(nraw[0]), "v"(nraw[1]), "v"(nraw[2]), "v"(nraw[3]) : "memory");
     };
     const int stride = 8 * nx;
     const Pos step = decompose(stride);
@@ -419,15 +440,12 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     };
     int item = xcd * nx + wx;                                    // wave-uniform
     Pos nxt = decompose(item);
-    unsigned raw[P] = {};
-    f4 rawv = {};
+    unsigned raw[P] = {}, nraw[P] = {};
+    f4 rawv = {}, nrawv = {};
     if (!U8 && !TAIL && item < total) {
-        issue_raw(geo(nxt), raw, rawv);
-        // the first group has no older stores in front of its pixels: drain (the counted wait in the loop assumes them)
-        if constexpr (MODE == 1)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawv) :: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) :: "memory");
+        issue_raw(geo(nxt), nraw, nrawv);
+        // the first group has no older stores in front of its pixels: drain here (the counted wait in the loop assumes them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     float a0[2];                                                 // conv0's A fragments (loop-invariant)
 #pragma unroll
@@ -459,10 +477,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         {
             if constexpr (!U8 && !TAIL) {
                 // the input pixels of this group have landed; the previous group's stores may still be in flight
-                if constexpr (MODE == 1)
-                    asm volatile(BALF_S1_WAIT_IN : "+v"(rawv) :: "memory");
-                else
-                    asm volatile(BALF_S1_WAIT_IN : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) :: "memory");
+                take_raw(raw, rawv, nraw, nrawv);
             }
 #pragma unroll
             for (int p = 0; p < P; ++p) {
@@ -486,7 +501,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
 #undef BALF_S1_UB
             }
         }
-        if constexpr (!U8 && !TAIL) issue_raw(geo(nxt), raw, rawv);   // next group's pixels (4 loads or 1, always)
+        if constexpr (!U8 && !TAIL) issue_raw(geo(nxt), nraw, nrawv);   // next group's pixels (4 loads or 1, always)
         STAMP(1);   // input -> conv0 B fragments (waits for the prefetched pixels), next group's loads issued
         auto conv0 = [&](f4 (&x0v)[2][P]) {                      // x0 = relu(conv0(X)); bit-identical every time
             s1_bias(x0v, par + kS1pConv0B, q);

@@ -11,12 +11,33 @@ There is no CPU path; a CPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import warnings
+from operator import attrgetter
 
 import torch
 import torch.nn as nn
 
 from .. import _lib, arch, ops
 from .._lib import BalfHipError, check, lib
+
+# The packed-weight cache must notice every way a checkpoint can change under it, and a single-image call (the
+# reference's only calling pattern, /root/reference/demo/demo_match.py:29) must not pay for that: walking the 167 state
+# tensors through nn.Module.__getattr__ cost 130 us per forward.  So: (i) an epoch counter bumped by torch's global
+# registration hooks whenever ANY module gets a parameter or buffer (re)registered (assignment, load_state_dict(assign=True))
+# and by this module's _apply (.to(), .cuda(), .float(): buffers are replaced there), which invalidates the cached tensor
+# LIST; (ii) per call, the sum of the version counters of the cached tensors (in-place updates: load_state_dict, copy_,
+# optimiser steps), ~10 us.
+_EPOCH = [0]
+
+
+def _bump_epoch(*_args, **_kwargs):
+    _EPOCH[0] += 1
+
+
+nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
+nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
+_VERSION = attrgetter("_version")
 
 
 class _Holder(nn.Module):
@@ -78,9 +99,10 @@ class MLP_MA_DECODER(nn.Module):
         head.norm = nn.BatchNorm2d(a["cell_size"] ** 2 + 1)
         self.detector_head = head
         self.precision = precision
-        self._tensors = None           # (module, attribute) of every state tensor, see _state_tensors
+        self._tensors = None           # (epoch, the state tensors in state_dict order), see _state_tensors
         self._packed = None            # (device blob, key) cache; rebuilt when parameters change
         self._packed_key = None
+        self._fp16_checked = None      # key of the weights the split-f16 path was last validated for (see _check_fp16_range)
 
     # ---- weights -> packed device blob -------------------------------------------------------
     def _precision_code(self) -> int:
@@ -89,16 +111,26 @@ class MLP_MA_DECODER(nn.Module):
         except KeyError:
             raise ValueError(f"precision must be 'fp32' or 'fp16', got {self.precision!r}")
 
+    def _apply(self, fn, *args, **kwargs):
+        _bump_epoch()                  # .to() / .cuda() / .float() replace buffers (and may replace parameters)
+        return super()._apply(fn, *args, **kwargs)
+
     def _state_tensors(self):
-        """The 167 state tensors in state_dict order, collected once (module structure is fixed after __init__);
-        ``load_state_dict`` / ``.to()`` / in-place updates change data pointers or versions, which the key tracks."""
-        if self._tensors is None:
-            self._tensors = [(m, n) for m in self.modules() for n in
-                             list(m._parameters.keys()) + [b for b in m._buffers.keys() if b not in m._non_persistent_buffers_set]]
-        return [getattr(m, n) for m, n in self._tensors]
+        """The 167 state tensors in state_dict order; the list is rebuilt only when a parameter or buffer was
+        (re)registered somewhere since (module-level epoch), in-place changes show in the version counters."""
+        if self._tensors is None or self._tensors[0] != _EPOCH[0]:
+            ts = [getattr(m, n) for m in self.modules() for n in
+                  list(m._parameters.keys()) + [b for b in m._buffers.keys() if b not in m._non_persistent_buffers_set]]
+            self._tensors = (_EPOCH[0], ts)
+        return self._tensors[1]
 
     def _state_key(self, device):
-        return (str(device), self.precision, tuple(_lib.tensor_key(t) for t in self._state_tensors()))
+        ts = self._state_tensors()
+        try:
+            ver = sum(map(_VERSION, ts))
+        except RuntimeError:           # inference tensors (a model moved under torch.inference_mode()) track no versions
+            ver = tuple(t.data_ptr() for t in ts)     # ... and cannot be modified in place
+        return (self._tensors[0], str(device), self.precision, ver)
 
     def packed_weights(self, device) -> torch.Tensor:
         key = self._state_key(device)
@@ -122,7 +154,35 @@ class MLP_MA_DECODER(nn.Module):
             check(l.balf_pack_weights(ptrs, n, prec, blob.data_ptr(), nbytes), "balf_pack_weights")
             self._packed = blob.to(device)
             self._packed_key = key
+            if self.precision == "fp16" and self._fp16_checked != key[:2] + key[3:]:
+                self._check_fp16_range(device, key)
         return self._packed
+
+    def _check_fp16_range(self, device, key):
+        """Once per set of weights, when the split-f16 blob is (re)built: the default path carries every MFMA operand
+        as two f16 halves, and an activation or weight beyond +-6.5e4 turns into inf/NaN without any trap (split16.h).
+        A checkpoint is therefore tried on three small images (noise, black, white) against the exact-fp32 kernels; if the
+        score maps disagree or are not finite the module switches itself to ``precision='fp32'`` (still the HIP
+        library, ~2.5x slower) and says so -- or raises with BALF_FP16_STRICT=1."""
+        self._fp16_checked = key[:2] + key[3:]
+        if os.environ.get("BALF_FP16_CHECK", "1") == "0":
+            return
+        g = torch.Generator(device="cpu").manual_seed(1)
+        x = torch.stack([torch.rand((3, 128, 128), generator=g), torch.zeros((3, 128, 128)), torch.ones((3, 128, 128))])
+        was_training = self.training
+        try:
+            self.training = False
+            self.validate_fp16(x.to(device))
+        except BalfHipError as e:
+            if os.environ.get("BALF_FP16_STRICT") == "1":
+                raise
+            warnings.warn(f"balf_amd: this checkpoint is outside the range of the split-f16 path ({e}); "
+                          "switching this model to precision='fp32' (exact-fp32 MFMA kernels)", RuntimeWarning)
+            self.precision = "fp32"
+            self._packed = None
+            self.packed_weights(device)
+        finally:
+            self.training = was_training
 
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, want_logits: bool = True):

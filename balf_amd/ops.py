@@ -10,21 +10,30 @@ import torch
 from . import _lib
 from ._lib import BalfHipError, check, current_stream_ptr, lib, require_gpu_tensor
 
-_workspaces: Dict[Tuple[str, int, int], torch.Tensor] = {}
+_workspaces: Dict[Tuple[str, int, int], torch.Tensor] = {}      # insertion order = least recently used first
+_MAX_STREAMS_PER_TAG = 2        # the forward workspace of 8 x 1088x1920 is ~7 GB: a process that keeps creating streams
+                                # must not pin one per stream it ever used
 
 
 def _workspace(tag: str, device, nbytes: int) -> torch.Tensor:
     """Caller-owned scratch (the library never allocates), cached per (purpose, device, STREAM) and grown on demand.
     Kernels of one stream run in order, so one buffer per stream is race-free; two streams (or two models driven from
-    two streams) get two buffers.  A buffer that is replaced by a larger one stays referenced by the caching allocator's
-    stream ordering: it was allocated and last used on this very stream."""
+    two streams) get two buffers.  A buffer that is replaced by a larger one -- or evicted: at most _MAX_STREAMS_PER_TAG
+    streams per (purpose, device) keep theirs, least recently used first out -- is handed back to the caching allocator,
+    which re-issues it in the order of the stream it was allocated and last used on.  (A raw stream handle may be
+    recycled for a new stream after its owner is destroyed; the entry it then finds was last used on the destroyed
+    stream, whose work the runtime completes before the handle is reused.)"""
     dev_index = device.index if device.index is not None else torch.cuda.current_device()
     key = (tag, dev_index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _workspaces.get(key)
+    ws = _workspaces.pop(key, None)
     if ws is None or ws.numel() < nbytes:
+        ws = None                                            # drop the smaller buffer before asking for the larger one
         with torch.cuda.device(device):
             ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+        same = [k for k in _workspaces if k[0] == tag and k[1] == dev_index]
+        for k in same[:max(0, len(same) - (_MAX_STREAMS_PER_TAG - 1))]:
+            del _workspaces[k]
+    _workspaces[key] = ws                                    # (re)inserted last: most recently used
     return ws
 
 

@@ -61,6 +61,30 @@ def test_asm_load_kernels_do_not_spill(tmp_path):
     assert checked == 2
 
 
+def test_hand_counted_vmcnt_waits_cover_their_loads():
+    """ADVICE r2 / DESIGN 4.3e: in the built code of the two float-input stage-1 kernels every load of the main loop is
+    covered by a counted wait before anything touches its destination, and nothing (no compiler-inserted copy) reads the
+    destination between the load and that wait.  The round-2 build FAILED this check: hipcc copied the prefetched pixels
+    out of the load's destination register in front of the wait (tools/vmcnt_audit.py)."""
+    import importlib.util
+    for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"):
+        if not os.path.exists(os.path.join(LLVM, t)):
+            pytest.skip(f"{t} not available")
+    spec = importlib.util.spec_from_file_location(
+        "vmcnt_audit", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "vmcnt_audit.py"))
+    va = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(va)
+    kernels = va.disassemble(_lib.LIB_PATH, r"stage1_kernel16ILi[01]ELb0")
+    assert len(kernels) == 2, list(kernels)
+    for name, ins in kernels.items():
+        problems, checked, margins = va.audit(ins)
+        assert not problems, (name, problems)
+        grid = "ILi0E" in name
+        assert checked == (4 if grid else 9), (name, checked)          # 4 pixel loads | 8 u' rows + 1 pixel load
+        assert all(young >= n for n, young in margins), margins
+        assert {n for n, _ in margins} == ({8} if grid else {1, 8}), margins
+
+
 def test_table_gelu_kernels_have_no_static_lds(tmp_path):
     """The table-GELU kernels (stage1_f16.h: gelu_lut_n, stage_cs_f16.h: gelu_log_n) use the masked index bits as the LDS
     ADDRESS of the table entry: the table is the first region of the dynamic LDS block, which starts at LDS address 0 only

@@ -260,3 +260,56 @@ def test_f16_split_operand_range():
     m.load_state_dict(_scaled_state(3.0e4))
     with torch.inference_mode(), pytest.raises(BalfHipError):
         m.validate_fp16(x, tol=PROB_TOL)
+
+
+def test_checkpoint_outside_f16_range_switches_to_fp32(monkeypatch):
+    """the default (split-f16) path must not return garbage for a checkpoint whose operands leave the f16
+    range.  When the f16 blob is built the module tries it against the fp32 kernels; on failure it warns and runs fp32
+    (BALF_FP16_STRICT=1: raises)."""
+    from balf_amd.model import get_model
+    from balf_amd._lib import BalfHipError
+    sd = synth.synthetic_state_dict(cases.WEIGHT_SEED)
+    sd["down1.conv.0.weight"] = sd["down1.conv.0.weight"] * 3.0e5          # x0 ~ 1e5: beyond f16 before the first LayerNorm
+    m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m.load_state_dict(sd)
+    m = m.eval().to("cuda:0")
+    assert m.precision == "fp16"
+    x = cases.forward_input(1, 64, 64, 3).to("cuda:0")
+    with pytest.warns(RuntimeWarning, match="outside the range of the split-f16 path"):
+        out = m(x)
+    assert m.precision == "fp32" and bool(torch.isfinite(out["prob"]).all())
+    with torch.no_grad():
+        ref = O.detector_forward(sd, x.cpu())["prob"].numpy()
+    assert np.abs(out["prob"].cpu().numpy() - ref).max() < PROB_TOL
+    m2 = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m2.load_state_dict(sd)
+    m2 = m2.eval().to("cuda:0")
+    monkeypatch.setenv("BALF_FP16_STRICT", "1")
+    with pytest.raises(BalfHipError):
+        m2(x)
+    # a well-scaled checkpoint stays on the split path, silently
+    m3 = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m3.load_state_dict(synth.synthetic_state_dict(cases.WEIGHT_SEED))
+    m3 = m3.eval().to("cuda:0")
+    import warnings as W
+    with W.catch_warnings():
+        W.simplefilter("error")
+        m3(x)
+    assert m3.precision == "fp16"
+
+
+def test_workspace_cache_is_bounded_per_stream():
+    """one ~7 GB forward workspace per stream ever used must not stay pinned."""
+    from balf_amd import ops
+    ops.release_workspaces()
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream(device=dev) for _ in range(5)]
+    for s in streams:
+        with torch.cuda.stream(s):
+            ops._workspace("forward", dev, 1 << 20)
+    assert sum(1 for k in ops._workspaces if k[0] == "forward") <= ops._MAX_STREAMS_PER_TAG
+    with torch.cuda.stream(streams[-1]):
+        a = ops._workspace("forward", dev, 1 << 20)
+        assert ops._workspace("forward", dev, 1 << 19) is a            # reused, not regrown
+    torch.cuda.synchronize()
+    ops.release_workspaces()

@@ -191,3 +191,35 @@ def test_repeatability_host_helpers_match_reference_golden():
     kp = np.stack([src[:, 1] * 0.3 + 1, src[:, 0] * 0.3 + 1, src[:, 2], src[:, 3]], axis=1)
     assert np.array_equal(R.check_common_points(kp, ms), g["helpers.common"])
     assert np.array_equal(R.select_top_k(kp, 40), g["helpers.topk"])
+
+
+def test_packed_weight_cache_key_notices_every_kind_of_change():
+    """The per-call key of the packed-weight cache (a version sum over a cached tensor list + a registration epoch) must
+    change on in-place updates, load_state_dict (copy and assign), dtype / device moves and parameter replacement."""
+    import torch
+    from balf_amd import arch
+    from balf_amd.model import get_model
+    from balf_amd.utils import synth
+    m = get_model.load_model(arch.DEFAULT_MODEL_CFG).eval()
+    seen = [m._state_key("cpu")]
+
+    def changed():
+        k = m._state_key("cpu")
+        assert k not in seen
+        seen.append(k)
+    assert m._state_key("cpu") == seen[0]                  # stable while nothing changes
+    with torch.no_grad():
+        m.down3.conv2.bias.add_(1.0)
+    changed()
+    m.load_state_dict(synth.synthetic_state_dict(1))
+    changed()
+    m.load_state_dict(synth.synthetic_state_dict(2), assign=True)
+    changed()
+    m.down1.conv[0].weight = torch.nn.Parameter(torch.zeros(32, 3))
+    changed()
+    assert m._state_tensors()[0] is m.down1.conv[0].weight
+    m.double()
+    changed()
+    m.precision = "fp32"
+    changed()
+    assert len(m._state_tensors()) == 167
