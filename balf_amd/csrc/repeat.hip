@@ -12,12 +12,10 @@
 //   rep_scan_kernel    exclusive scan of the per-row counts
 //   rep_fill_kernel    one wave per source point: ordered compaction of the candidate pairs (key = overlap bits,
 //                      value = flat index i*Nd + j, written in flat order)
-//   hipcub radix sort  stable, descending by overlap => equal overlaps stay in flat-index order
+//   rep_sort_kernel    stable LSD radix sort, descending by overlap => equal overlaps stay in flat-index order
 //   rep_greedy_kernel  one wave walks the sorted candidates 64 at a time; visited bitmaps in LDS; the error sum is
 //                      accumulated in the reference's order
 // The candidate count is data dependent, so balf_repeatability synchronises the stream once to read it.
-#include <hipcub/hipcub.hpp>
-
 #include "common.h"
 
 namespace balf {
@@ -183,20 +181,85 @@ __global__ void homography_kernel(const double *pts, int n, const double *h, dou
     out[4 * i + 3] = pts[4 * i + 3];
 }
 
-size_t sort_temp_bytes(int max_edges) {
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, (const unsigned long long *)nullptr,
-                                                       (unsigned long long *)nullptr, (const unsigned *)nullptr,
-                                                       (unsigned *)nullptr, max_edges);
-    return bytes;
+// Stable LSD radix sort of (key, value) pairs, DESCENDING by the 64-bit key, 4 bits per pass, one workgroup of 16
+// waves.  Wave w owns the contiguous range [w * per, (w + 1) * per) of the input and walks it 64 elements at a time, so
+// "input order" is (wave, row, lane) and a pass keeps it among equal digits: per row the lane's rank among the lanes with
+// its digit comes from a ballot, per wave the digit counts go through a [digit][wave] table in LDS whose exclusive scan
+// (digit-major) gives every wave its output cursor per digit.  Passes whose digit is the same for all keys are skipped
+// (overlaps lie in [1 - overlap_err, 1]: the sign, exponent and leading mantissa digits agree), so the 16 possible passes
+// are ~11 in practice.  The pairs ping-pong between (k0, v0) and (k1, v1); the result always ends in (k1, v1).
+// (Round 2 called hipcub::DeviceRadixSort here; the library now has no third-party device code.)
+constexpr int kSortWaves = 16;
+__global__ __launch_bounds__(kSortWaves * 64) void rep_sort_kernel(unsigned long long *k0, unsigned *v0, unsigned long long *k1,
+                                                                  unsigned *v1, int n) {
+    __shared__ int hist[16][kSortWaves];
+    __shared__ int uniform_digit;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = ((n + kSortWaves - 1) / kSortWaves + 63) / 64 * 64;
+    const int lo = wave * per < n ? wave * per : n, hi = lo + per < n ? lo + per : n;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long *kin = k0, *kout = k1;
+    unsigned *vin = v0, *vout = v1;
+    for (int shift = 0; shift < 64; shift += 4) {
+        int cnt[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) cnt[d] = 0;
+        for (int e0 = lo; e0 < hi; e0 += 64) {
+            const int e = e0 + lane;
+            const int dig = e < hi ? 15 - (int)((kin[e] >> shift) & 15ull) : -1;       // descending: largest digit first
+#pragma unroll
+            for (int d = 0; d < 16; ++d) cnt[d] += __popcll(__ballot(dig == d));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) hist[d][wave] = cnt[d];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0, uni = -1;
+            for (int d = 0; d < 16; ++d) {
+                int tot = 0;
+                for (int w = 0; w < kSortWaves; ++w) { const int c = hist[d][w]; hist[d][w] = run; run += c; tot += c; }
+                if (tot == n) uni = d;
+            }
+            uniform_digit = uni;
+        }
+        __syncthreads();
+        const bool skip = uniform_digit >= 0;                    // every key has this digit: the pass would be the identity
+        if (!skip) {
+            int cur[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) cur[d] = hist[d][wave];
+            for (int e0 = lo; e0 < hi; e0 += 64) {
+                const int e = e0 + lane;
+                unsigned long long k = 0; unsigned v = 0;
+                if (e < hi) { k = kin[e]; v = vin[e]; }
+                const int dig = e < hi ? 15 - (int)((k >> shift) & 15ull) : -1;
+                int dst = 0;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const unsigned long long b = __ballot(dig == d);
+                    if (dig == d) dst = cur[d] + __popcll(b & below);
+                    cur[d] += __popcll(b);
+                }
+                if (e < hi) { kout[dst] = k; vout[dst] = v; }
+            }
+        }
+        __syncthreads();                                         // the pass's writes are visible to the whole workgroup; hist is free
+        if (!skip) {
+            unsigned long long *tk = kin; kin = kout; kout = tk;
+            unsigned *tv = vin; vin = vout; vout = tv;
+        }
+    }
+    if (kin != k1)                                               // (uniform) the sorted pairs sit in (k0, v0): copy
+        for (int e = threadIdx.x; e < n; e += kSortWaves * 64) { k1[e] = kin[e]; v1[e] = vin[e]; }
 }
 
 struct RepWs {
     int *cnt_s, *cnt_m, *poss, *off_s, *off_m, *totals;
     unsigned long long *key_s, *key_m, *key_out;      // candidate lists (both filled in one pass), sorted keys
     unsigned *val_s, *val_m, *val_out;
-    void *temp;
-    size_t temp_bytes, total;
+    size_t total;
 };
 
 RepWs rep_layout(char *base, int ns, int max_edges) {
@@ -209,8 +272,6 @@ RepWs rep_layout(char *base, int ns, int max_edges) {
     w.key_out = (unsigned long long *)take((size_t)max_edges * 8);
     w.val_s = (unsigned *)take((size_t)max_edges * 4); w.val_m = (unsigned *)take((size_t)max_edges * 4);
     w.val_out = (unsigned *)take((size_t)max_edges * 4);
-    w.temp_bytes = sort_temp_bytes(max_edges);
-    w.temp = take(w.temp_bytes);
     w.total = o;
     return w;
 }
@@ -249,12 +310,9 @@ extern "C" int balf_repeatability(const double *src_dev, int ns, const double *d
     const int cap = ns < nd ? ns : nd;
     for (int which = 0; which < 2; ++which) {
         const int ne = totals[which];
-        const unsigned long long *kin = which ? w.key_m : w.key_s;
-        const unsigned *vin = which ? w.val_m : w.val_s;
-        if (ne > 0) {
-            size_t tb = w.temp_bytes;
-            if (hipcub::DeviceRadixSort::SortPairsDescending(w.temp, tb, kin, w.key_out, vin, w.val_out, ne, 0, 64, st) != hipSuccess)
-                return BALF_ERR_LAUNCH;
+        if (ne > 0) {       // (sorts in place between the candidate list and the output buffers; the list is not needed again)
+            rep_sort_kernel<<<1, kSortWaves * 64, 0, st>>>(which ? w.key_m : w.key_s, which ? w.val_m : w.val_s, w.key_out, w.val_out, ne);
+            BALF_LAUNCH_CHECK();
         }
         rep_greedy_kernel<<<1, 64, 0, st>>>(w.key_out, w.val_out, ne, nd, counts_dev + which, errors_dev + which,
                                             which ? corr_m_dev : corr_s_dev, cap);

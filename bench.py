@@ -284,6 +284,39 @@ def stub_main(args, json_fd):
     dist.destroy_process_group()
 
 
+def single_image_latency(model, dev, h, w, k, calls=60):
+    """Median over `calls` single-image detect_batch_u8 calls (uint8 gray image resident in HBM -> forward -> NMS -> top-K),
+    each followed by a synchronisation.  wall = host clock around call + sync; device = hipEvents recorded on the launch
+    stream right before and after the call (first launch to last kernel's end, launch gaps included); kernels = sum of the
+    kernels' own durations (a separate profiled pass).  host_overhead_us = wall - device."""
+    import statistics
+    img = torch.from_numpy(synthetic_batch(h, w, 0, 1)).to(dev)
+    for _ in range(5):
+        pipeline.detect_batch_u8(model, img, 15, 15, k)
+    torch.cuda.synchronize(dev)
+    walls, devs = [], []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        e0.record()
+        out = pipeline.detect_batch_u8(model, img, 15, 15, k)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        walls.append((time.perf_counter() - t0) * 1e3)
+        devs.append(e0.elapsed_time(e1))
+    ops.profile_begin()
+    for _ in range(10):
+        pipeline.detect_batch_u8(model, img, 15, 15, k)
+    torch.cuda.synchronize(dev)
+    prof = ops.profile_end()
+    kern = sum(v[0] for v in prof.values()) / 10
+    wall, devm = statistics.median(walls), statistics.median(devs)
+    return {"workload": f"1 x {w}x{h} uint8 gray, top-{k} (detect_batch_u8 + sync)", "calls": calls, "wall_ms": wall,
+            "device_ms": devm, "kernels_ms": kern, "host_overhead_us": (wall - devm) * 1e3,
+            "wall_minus_kernels_us": (wall - kern) * 1e3, "wall_ms_p90": sorted(walls)[int(0.9 * calls)],
+            "images_per_s": 1e3 / wall, "launches": sum(v[1] for v in prof.values()) // 10, "keypoints": int(out[2][0])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -511,6 +544,12 @@ def main():
         model.precision = args.precision
         torch.cuda.empty_cache()
 
+    # batch-1 latency: the only way the reference ever calls the model (/root/reference/demo/demo_match.py:29,
+    # balf/utils/train_utils.py:428) -- one uint8 image in, keypoints out, a synchronisation per call
+    latency = None
+    if world == 1 and args.other_configs and (h, w, b) == (1080, 1920, 32):
+        latency = [single_image_latency(model, dev, hh, ww, kk) for (hh, ww, kk) in ((480, 640, 1000), (1080, 1920, 2000))]
+
     if rank == 0:
         ips = head["images_per_s"]
         nms_bytes = b * (4.0 * h * w + 8.0 * k + 4.0)
@@ -545,6 +584,7 @@ def main():
             "kernels_ms_per_step": head["kernels_ms_per_step"],
             "other_precision": other,
             "other_configs": other_cfgs,
+            "batch1_latency": latency,
         }
         if world == 1 and args.cpu_images > 0:
             n = min(args.cpu_images, b)
