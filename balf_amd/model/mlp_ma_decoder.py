@@ -165,8 +165,8 @@ class MLP_MA_DECODER(nn.Module):
         score maps disagree or are not finite the module switches itself to ``precision='fp32'`` (still the HIP
         library, ~2.5x slower) and says so -- or raises with BALF_FP16_STRICT=1."""
         self._fp16_checked = key[:2] + key[3:]
-        if os.environ.get("BALF_FP16_CHECK", "1") == "0":
-            return
+        if os.environ.get("BALF_FP16_CHECK", "1") == "0" or getattr(self, "_validating", False):
+            return                     # switched off, or the caller is validate_fp16 itself (it reports on ITS input)
         g = torch.Generator(device="cpu").manual_seed(1)
         x = torch.stack([torch.rand((3, 128, 128), generator=g), torch.zeros((3, 128, 128)), torch.ones((3, 128, 128))])
         was_training = self.training
@@ -218,13 +218,16 @@ class MLP_MA_DECODER(nn.Module):
         weight beyond +-6.5e4 saturates (split16.h) -- LayerNorm keeps most operands O(1), but the stage inputs, the
         gated branch, the RCAB hidden layer and the head input scale with the checkpoint's weights."""
         keep = self.precision
+        nested = getattr(self, "_validating", False)
         try:
+            self._validating = True
             self.precision = "fp32"
             ref = self.forward(x, want_logits=False)["prob"]
             self.precision = "fp16"
             out = self.forward(x, want_logits=False)["prob"]
         finally:
             self.precision = keep
+            self._validating = nested
         if not bool(torch.isfinite(out).all()):
             raise BalfHipError("the split-f16 path produced non-finite values on this input: an operand left the f16 "
                                "range (|v| < 6.5e4); use precision='fp32' for this checkpoint")
