@@ -30,6 +30,12 @@ constexpr float kGeluLutL = 6.0f;
 constexpr int kGeluLogM = 256;
 constexpr int kGeluLogEntries = 3 * kGeluLogM + 1;
 
+// Which stages' split-f16 weights are packed as fragments of v_mfma_f32_32x32x16_f16 (weights.hip: pack_frags32) instead
+// of v_mfma_f32_16x16x32_f16 (pack_frags16); the fp32 blob is not affected.  Stage s's OUTPUT activation (the next stage's
+// input X, fragment format in HBM) follows the format of the stage that CONSUMES it.
+constexpr bool kFmt32[kStages] = {true, false, false, false};
+constexpr bool kFmt32Head = false;
+
 struct BranchOff {                // GridGmlpLayer / BlockGmlpLayer
     int ln_g, ln_b;               // .norm
     int d1_w, d1_b;               // .dense1  [2C, C]   frags

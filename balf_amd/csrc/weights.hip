@@ -106,6 +106,33 @@ void pack_frags16(float *dst_region, const float *W, int N, int K, int Npad, boo
                 }
 }
 
+// Split-f16 fragments for v_mfma_f32_32x32x16_f16 (the 32x32 kernels: layout.h kFmt32).  Weight tile (R, s) = 32 output
+// rows x 16 inputs occupies 2 KiB: [hi: 64 lanes x 8 halves][lo: ...]; lane (m = lane & 31, h = lane >> 5), half j holds
+//   permuted:  W[row(R, m)][16 s + 8 (j >> 2) + 4 h + (j & 3)]  -- the K order of the register chain: an accumulator's
+//              registers 8 s .. 8 s + 7 of lane half h (channels 8 g + 4 h + r, g = 2 s, 2 s + 1) are K-step s' K-slots;
+//   natural:   W[row(R, m)][16 s + 8 h + j]                     -- the token-mix matrix (K = token index read linearly
+//              from the transposed tile in LDS).
+// row(R, m) = 32 R + m, or for the token-mix matrix (`token_rows`) 2 m + R: output tile R holds the tokens the lane
+// columns of pixel tile R carry (token t = 2 n + p, stage1_f16.h).
+void pack_frags32(float *dst_region, const float *W, int N, int K, int Npad, bool permuted, bool token_rows) {
+    _Float16 *dst = reinterpret_cast<_Float16 *>(dst_region);
+    const int KS = K / 16;
+    for (int R = 0; R < Npad / 32; ++R)
+        for (int s = 0; s < KS; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int m = lane & 31, h = lane >> 5;
+                    const int n = token_rows ? 2 * m + R : 32 * R + m;
+                    const int k = permuted ? 16 * s + 8 * (j >> 2) + 4 * h + (j & 3) : 16 * s + 8 * h + j;
+                    const float w = n < N ? W[(size_t)n * K + k] : 0.0f;
+                    const _Float16 hi = (_Float16)w;
+                    const _Float16 lo = (_Float16)(w - (float)hi);
+                    const size_t tile = ((size_t)R * KS + s) * 1024;            // halves per 2 KiB tile
+                    dst[tile + lane * 8 + j] = hi;
+                    dst[tile + 512 + lane * 8 + j] = lo;
+                }
+}
+
 // LayerNorm(x; gamma, beta) followed by Linear(W, b):  W (n * gamma + beta) + b = (W diag gamma) n + (W beta + b)
 // where n = (x - mean) * rstd.  Folding the affine part into the Linear removes 3 VALU ops per element
 // from the kernels (the f32 MFMA shares its pipe with the VALU, so they are not free).
@@ -155,12 +182,15 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
     memset(blob, 0, (size_t)kLayout.total * sizeof(float));
     const bool f16 = precision == BALF_PREC_FP16;
     // MFMA-operand weights: fp32 A fragments, or split-f16 fragments in the same region
+    bool fmt32 = false;                 // (set per stage below) split-f16 fragments of the 32x32x16 MFMA
     auto pack = [&](float *dst, const float *W, int N, int K, int Npad) {
-        if (f16) pack_frags16(dst, W, N, K, Npad, true);
+        if (f16 && fmt32) pack_frags32(dst, W, N, K, Npad, true, false);
+        else if (f16) pack_frags16(dst, W, N, K, Npad, true);
         else pack_frags(dst, W, N, K, Npad);
     };
     for (int s = 0; s < kStages; ++s) {
         const int C = kC[s], Cin = kCin[s];
+        fmt32 = kFmt32[s];
         const StageOff &S = kLayout.st[s];
         const float *const *t = tensors + s * kTensorsPerStage;
         if (s == 0) copy(blob + S.conv0_w, t[0], (size_t)C * Cin);
@@ -182,7 +212,8 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
             copy(blob + B.d1_b, bf.data(), 2 * C);
             copy(blob + B.gln_g, u[4], C);
             copy(blob + B.gln_b, u[5], C);
-            if (f16) pack_frags16(blob + B.mix_w, u[6], kTokens, kTokens, kTokens, false);
+            if (f16 && fmt32) pack_frags32(blob + B.mix_w, u[6], kTokens, kTokens, kTokens, false, true);
+            else if (f16) pack_frags16(blob + B.mix_w, u[6], kTokens, kTokens, kTokens, false);
             else pack_frags(blob + B.mix_w, u[6], kTokens, kTokens, kTokens);
             copy(blob + B.mix_b, u[7], kTokens);
             pack(blob + B.d2_w, u[8], C, C, C);
@@ -206,6 +237,7 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
         copy(blob + S.conv2_b, t[39], C);
     }
     const float *const *h = tensors + kStages * kTensorsPerStage;
+    fmt32 = kFmt32Head;
     pack(blob + kLayout.head_w, h[0], kHeadN, kC[3], kHeadNPad);
     copy(blob + kLayout.head_b, h[1], kHeadN);
     for (int c = 0; c < kHeadN; ++c) {

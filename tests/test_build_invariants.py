@@ -80,9 +80,9 @@ def test_hand_counted_vmcnt_waits_cover_their_loads():
         problems, checked, margins = va.audit(ins)
         assert not problems, (name, problems)
         grid = "ILi0E" in name
-        assert checked == (4 if grid else 9), (name, checked)          # 4 pixel loads | 8 u' rows + 1 pixel load
+        assert checked == (4 if grid else 10), (name, checked)         # 4 pixel loads | 8 u' fragments + 2 pixel loads
         assert all(young >= n for n, young in margins), margins
-        assert {n for n, _ in margins} == ({8} if grid else {1, 8}), margins
+        assert {n for n, _ in margins} == ({8} if grid else {2, 8}), margins
 
 
 def test_table_gelu_kernels_have_no_static_lds(tmp_path):

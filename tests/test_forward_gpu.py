@@ -49,6 +49,9 @@ def test_f16_split_forward_vs_reference_golden(model16, name):
     lerr = np.abs(out["logits"].cpu().numpy() - f[name + ".logits"]).max()
     print(name, "f16x3 prob err", perr, "logit err", lerr)
     assert perr < PROB_TOL and lerr < LOGIT_TOL
+    # what the split path actually achieves (4e-6 / 2e-5): a lost residual half or a slightly wrong squeeze-excite scale
+    # shows up as ~5e-4 -- inside the north-star tolerance, outside this gate (round 3: a compiler mis-fold of a row swap)
+    assert perr < 2e-5 and lerr < 1.5e-4
 
 
 def test_f16_split_vga_detections(model16):
