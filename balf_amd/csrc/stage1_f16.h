@@ -491,21 +491,14 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         const Geo g = geo(nxt);
         if (item + stride < total) nxt = advance(nxt);           // (the last group re-requests its own pixels)
         const long pix0 = g.pix0;
-        if (U8) load_raw_u8(g, raw);
+        if (U8 && !TAIL) load_raw_u8(g, raw);                  // (tail: right before its conv0, see below)
         // (tail) plain loads, no prefetch across groups: three waves per SIMD cover the latency, and with few stores per
         // group there is no store queue to count around.  x1 as the block kernel left it, this image's SE scale.
         f16v x1t[TAIL ? 2 : 1];
         f4 sct[4];
         if constexpr (TAIL) {
-            if constexpr (!U8) {
-                const float *xp = A.X + (long)g.n * 3 * (long)hw + (long)g.y * W + g.x0;
-                const float2 va = *reinterpret_cast<const float2 *>(xp + (long)h * hw), vb = *reinterpret_cast<const float2 *>(xp + 2L * hw);
-                raw[0] = __builtin_bit_cast(unsigned, va.x); raw[1] = __builtin_bit_cast(unsigned, va.y);
-                raw[2] = __builtin_bit_cast(unsigned, vb.x); raw[3] = __builtin_bit_cast(unsigned, vb.y);
-            }
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                sct[gq] = *reinterpret_cast<const f4 *>(A.scale + (long)g.n * C + 8 * gq + 4 * h);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const f4 v = *reinterpret_cast<const f4 *>(A.R + (long)item * (64 * C) + ((p * 4 + gq) * 64 + lane) * 4);
@@ -516,16 +509,19 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         }
         STAMP(0);
         float bx[4];                                             // conv0's B operands
-        {
-            if constexpr (!U8 && !TAIL) {
-                // the input pixels of this group have landed; the previous group's stores may still be in flight
-                take_raw(raw, nraw);
-            }
+        auto make_bx = [&]() {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (U8) bx[i] = raw[i] < 256u ? par[kS1pLut + (raw[i] & 255u)] : 0.0f;
                 else bx[i] = __builtin_bit_cast(float, raw[i]);
             }
+        };
+        if constexpr (!TAIL) {
+            if constexpr (!U8) {
+                // the input pixels of this group have landed; the previous group's stores may still be in flight
+                take_raw(raw, nraw);
+            }
+            make_bx();
         }
         HL ub[(MODE == 1) ? P : 1][2];                           // block: u' rows of the lane's pixels (pre-split in HBM)
         if constexpr (MODE == 1) {
@@ -570,6 +566,19 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             f16v t[2];
             s1_bias(t, par + kS1pR2B, h);
             s1_linear<2>(t, wl + kS1R2, b);
+            // (the image's SE scale is requested here, not at the top: 16 registers less through the branch -- at three waves
+            // per SIMD the kernel otherwise spills; an L2 hit that conv0 covers)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) sct[gq] = *reinterpret_cast<const f4 *>(A.scale + (long)g.n * C + 8 * gq + 4 * h);
+            // the raw pixels likewise (plain loads; the tail has no prefetch across groups)
+            if constexpr (U8) load_raw_u8(g, raw);
+            else {
+                const float *xp = A.X + (long)g.n * 3 * (long)hw + (long)g.y * W + g.x0;
+                const float2 va = *reinterpret_cast<const float2 *>(xp + (long)h * hw), vb = *reinterpret_cast<const float2 *>(xp + 2L * hw);
+                raw[0] = __builtin_bit_cast(unsigned, va.x); raw[1] = __builtin_bit_cast(unsigned, va.y);
+                raw[2] = __builtin_bit_cast(unsigned, vb.x); raw[3] = __builtin_bit_cast(unsigned, vb.y);
+            }
+            make_bx();
             f16v x0v[2];
             conv0(x0v);
             // v = r + s t with r = x1 + x0, max over the 2x2 window: the lane's two tiles are horizontal neighbours, the

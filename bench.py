@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line.  `value` = images/s over all GPUs; `keypoints_per_s
                 steps: balf_profile_begin/end in include/balf_hip.h) against the HBM roof (8 TB/s) and the dense f16 /
                 f32 MFMA peak of MI355X_MICROARCH.md; `traffic` = measured HBM bytes per launch and `issue` = the share
                 of the SIMDs' issue cycles its vector + matrix instructions need, both from the committed rocprofv3
-                --pmc passes of this script (profiles/r2_pmc.json); "bound" says which limit the kernel sits at.
+                --pmc passes of this script (profiles/r3_pmc.json); "bound" says which limit the kernel sits at.
   index_match   BASELINE's "NMS index match vs CPU ref": the images of the CPU sample against the oracle.
   cpu_baseline  the CPU oracle (a port of the reference path, oracle/) on a bounded sample, rank 0, N = 1.
   other_configs the other BASELINE configurations that fit one GPU, a few steps each.
@@ -51,7 +51,7 @@ def _import_product():
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, dense f32 MFMA
 PEAK_FP16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA (the hardware's peak: the split path spends 3 products per MAC)
 PEAK_HBM_GBS = 8000.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r2_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r3_pmc.json")
 C_STAGE = [32, 64, 128, 256]
 CIN_STAGE = [3, 32, 64, 128]
 
@@ -101,7 +101,7 @@ def kernel_flops_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
 
 
 def pmc_profile(precision: str, mb: int, hp: int, wp: int):
-    """The committed PMC passes (profiles/r2_pmc.json, tools/pmc_json.py): per profile slot, HBM bytes per launch and the
+    """The committed PMC passes (profiles/r3_pmc.json, tools/pmc_json.py): per profile slot, HBM bytes per launch and the
     issue-slot accounting; None when they do not cover this shape."""
     if not (os.path.isfile(PMC_PROFILE) and mb == 8 and (hp, wp) == (1088, 1920)):
         return None
@@ -488,7 +488,7 @@ def main():
                 "achieved_GBps": tot * (b / mb) / (fwd_ms * 1e-3) / 1e9,
                 "frac_of_8TBps": tot * (b / mb) / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 "reference_points_bytes_per_px": {"algorithmic_minimum": 20.0, "fused_schedule_plan_fp16": 1100.0},
-                "source": "profiles/r2_pmc.json"}
+                "source": "profiles/r3_pmc.json"}
         return out_
 
     step = make_step(x, h, w, k)

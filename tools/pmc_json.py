@@ -6,7 +6,7 @@ bench.py's hipEvent timing uses) the measured HBM bytes per launch and the issue
   issue_share          = (VALU instructions * 2.6 + MFMA instructions * C) / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
                          what a SIMD charges with >= 2 waves resident (tools/ubench/mfma_valu_mix.hip): 2.6 cycles per
                          wave64 VALU instruction, C = 12.5 per v_mfma_f32_16x16x32_f16 issued beside vector work (16
-                         alone) or 32 per v_mfma_f32_16x16x4_f32 (no co-execution); GRBM_GUI_ACTIVE sums the 8 XCDs
+                         alone; the 32x32x16 instructions of stage 1 are counted as two) or 32 per v_mfma_f32_16x16x4_f32 (no co-execution); GRBM_GUI_ACTIVE sums the 8 XCDs
   valu_busy_share      = 4 * SQ_ACTIVE_INST_VALU / SIMD cycles,  mfma_busy_share = SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles:
                          how long the SIMDs' two execution pipes were occupied; their sum is ~1.07 for the stage-1 kernels
                          (the pipes overlap by a few per cent only: that sum is the roof these kernels sit under)
@@ -33,10 +33,10 @@ def slot_of(kernel: str):
     if m:
         st = [32, 64, 128, 256].index(int(m.group(1))) + 1
         return "stage%d_pool" % st if m.group(2) == "2" else "stage%d_%s_branch" % (st, "grid" if m.group(2) == "0" else "block")
-    m = re.match(r"stage_branch_kernel(?:16)?(?:_ns)?<(\d+), \d+, (\d)>", k)
+    m = re.match(r"stage_branch_kernel<(\d+), \d+, (\d)>", k)          # (the exact-fp32 path, detector.hip)
     if m:
         return "stage%d_%s_branch" % ([32, 64, 128, 256].index(int(m.group(1))) + 1, "grid" if m.group(2) == "0" else "block")
-    m = re.match(r"pool_kernel(?:16)?<(\d+)>", k)
+    m = re.match(r"pool_kernel<(\d+)>", k)
     if m:
         return "stage%d_pool" % ([32, 64, 128].index(int(m.group(1))) + 1)
     m = re.match(r"se_(?:reduce_)?kernel<(\d+)>", k)
@@ -44,7 +44,7 @@ def slot_of(kernel: str):
         return "stage%d_se" % ([32, 64, 128, 256].index(int(m.group(1))) + 1)
     if k.startswith("head_kernel"):
         return "stage4_head"
-    if "nms_tile_kernel" in k:
+    if re.match(r"nms_tile(15_vec)?_kernel", k):           # the detection path runs nms_tile15_vec_kernel (window 15)
         return "nms_tile"
     if "topk_select_kernel" in k:
         return "topk_select"
@@ -75,8 +75,10 @@ for prec in ("fp16", "fp32"):
              "fetch_kib_raw": c.get("FETCH_SIZE", 0.0), "write_kib": c.get("WRITE_SIZE", 0.0)}
         if c.get("SQ_WAVE_CYCLES"):
             simd_cycles = 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
+            # (stage 1 of the split-f16 path issues v_mfma_f32_32x32x16_f16: twice the MACs and cycles of a 16x16x32)
+            mf = c.get("SQ_INSTS_MFMA", 0.0) * (2.0 if prec == "fp16" and s.startswith("stage1_") and not s.endswith("_se") else 1.0)
             d.update({"waves": c["SQ_WAVES"], "valu_insts": c["SQ_INSTS_VALU"], "mfma_insts": c.get("SQ_INSTS_MFMA", 0.0),
-                      "issue_share": (c["SQ_INSTS_VALU"] * 2.6 + c.get("SQ_INSTS_MFMA", 0.0) * mfma_cycles) / simd_cycles,
+                      "issue_share": (c["SQ_INSTS_VALU"] * 2.6 + mf * mfma_cycles) / simd_cycles,
                       "wave_wait_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
                       "wave_issue_stall_share": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                       # execution-pipe occupancy per SIMD cycle: the vector ALU (4 cycles per wave64 instruction, 16 per

@@ -1,0 +1,87 @@
+// Micro-benchmark (development aid): what the matrix and vector pipes cost in POWER.  The forward runs at the package power
+// cap (tools/clock_probe.sh: ~1380 W, ~2.0 GHz instead of 2.4), so its speed is set by energy per image, not by issue slots
+// alone.  Each mode runs one instruction stream on every SIMD (2 waves per SIMD, as the stage kernels) for a few seconds
+// while tools/power_probe.sh samples rocm-smi; the program prints the achieved instruction rate.
+//   mode 0: v_mfma_f32_16x16x32_f16   1: v_mfma_f32_32x32x16_f16   2: v_fma_f32   3: v_exp_f32   4: 1 MFMA(16x16x32) : 6 fma
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/power_probe.hip -o tools/ubench/power_probe
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+typedef float f4x __attribute__((ext_vector_type(4)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k(float *out, int iters) {
+    float a[16];
+    for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 0.001f + i * 0.37f;
+    f4x acc[8];
+    f16x big[4];
+    for (int j = 0; j < 8; ++j) acc[j] = f4x{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 16; ++i) big[j][i] = 0.f;
+    h8 ha[2], hb[2];
+    unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    for (int v = 0; v < 2; ++v)
+        for (int i = 0; i < 8; ++i) {
+            s = s * 1664525u + 1013904223u; ha[v][i] = (_Float16)(((int)(s >> 20) - 2048) * 0.0007f);
+            s = s * 1664525u + 1013904223u; hb[v][i] = (_Float16)(((int)(s >> 20) - 2048) * 0.0007f);
+        }
+    const float m = 0.9991f, c = 0.0013f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (MODE == 0 || MODE == 4) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(ha[j & 1]), "v"(hb[j & 1]));
+            if (MODE == 1 && (j & 1) == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(big[j >> 1]) : "v"(ha[(j >> 1) & 1]), "v"(hb[(j >> 1) & 1]));
+            if (MODE == 2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (MODE == 3)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+            if (MODE == 4)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[(j * 6 + i) & 15]) : "v"(m), "v"(c));
+        }
+    }
+    float r = 0;
+    for (int i = 0; i < 16; ++i) r += a[i];
+    for (int j = 0; j < 8; ++j) r += acc[j][0];
+    for (int j = 0; j < 4; ++j) r += big[j][0];
+    out[blockIdx.x * 512 + threadIdx.x] = r;
+}
+
+int main(int argc, char **argv) {
+    const int mode = argc > 1 ? atoi(argv[1]) : 0;
+    const double secs = argc > 2 ? atof(argv[2]) : 4.0;
+    float *out;
+    (void)hipMalloc(&out, 256 * 512 * 4);
+    const int iters = 20000;
+    auto launch = [&]() {
+        switch (mode) {
+            case 0: hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, out, iters); break;
+            case 1: hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, out, iters); break;
+            case 2: hipLaunchKernelGGL(k<2>, dim3(256), dim3(512), 0, 0, out, iters); break;
+            case 3: hipLaunchKernelGGL(k<3>, dim3(256), dim3(512), 0, 0, out, iters); break;
+            default: hipLaunchKernelGGL(k<4>, dim3(256), dim3(512), 0, 0, out, iters); break;
+        }
+    };
+    launch();
+    (void)hipDeviceSynchronize();
+    const auto t0 = std::chrono::steady_clock::now();
+    long n = 0;
+    double el = 0;
+    do {
+        for (int i = 0; i < 4; ++i) launch();
+        (void)hipDeviceSynchronize();
+        n += 4;
+        el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } while (el < secs);
+    // per iteration and wave: 8 MFMA(16x16x32) | 4 MFMA(32x32x16) | 128 fma | 32 exp | 8 MFMA + 48 fma;  2048 waves
+    const double per_iter[5] = {8, 4, 128, 32, 8};
+    const double rate = n * (double)iters * per_iter[mode] * 2048 / el;
+    const char *what[5] = {"MFMA16x16x32", "MFMA32x32x16", "v_fma_f32", "v_exp_f32", "MFMA16x16x32 (+6 fma each)"};
+    printf("mode %d: %.3e %s wave-instructions/s over %.1f s (%.2f per SIMD per us)\n", mode, rate, what[mode], el, rate / 1024 / 1e6);
+    return 0;
+}
