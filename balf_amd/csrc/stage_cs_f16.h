@@ -111,9 +111,6 @@ __device__ __forceinline__ void cs_gelu(f4 (&t)[2][4]) {
         }
 }
 
-#ifndef BALF_CS_PRIO
-#define BALF_CS_PRIO 0       // experiment: wave priority raised inside the K loops (1) or lowered there (2)
-#endif
 #ifndef BALF_CS_SCHED
 #define BALF_CS_SCHED 1      // 1: a scheduling fence only behind the weight requests (measured best; 0: none, 2: also behind the MFMAs)
 #endif
@@ -183,8 +180,6 @@ __device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, con
                 for (int p = 0; p < 4; ++p) acc[t][p] = mfma16(w.a[s][t].hi, b[p].hi, acc[t][p]);
         }
     };
-    if (BALF_CS_PRIO == 1) __builtin_amdgcn_s_setprio(2);
-    if (BALF_CS_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     if constexpr (KSN <= 2) {
         compute(first, 0);
     } else {
@@ -202,8 +197,6 @@ __device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, con
             if (BALF_CS_SCHED >= 2) __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (BALF_CS_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-    if (BALF_CS_PRIO == 2) __builtin_amdgcn_s_setprio(2);
 }
 
 // All weight fragments of a Linear of this wave at once (the tail kernels: few live tensors, so a whole Linear's tiles

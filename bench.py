@@ -317,6 +317,47 @@ def single_image_latency(model, dev, h, w, k, calls=60):
             "images_per_s": 1e3 / wall, "launches": sum(v[1] for v in prof.values()) // 10, "keypoints": int(out[2][0])}
 
 
+def power_state_under_load(step, dev, seconds=2.5):
+    """Clock and package power while the step runs back to back (rocm-smi, sampled from a thread): the forward runs AT the
+    package power cap of the MI355X (~1380 W of 1400), which holds the shader clock near 2.0 GHz instead of the 2.4 GHz the
+    peak figures assume -- the roofline's `peak` is the nominal one, this field says what the silicon sustained."""
+    import re
+    import subprocess
+    import threading
+    samples = []
+
+    def sampler():
+        for _ in range(3):
+            try:
+                o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                d = next(iter(json.loads(o[o.index("{"):]).values()))
+                clk = re.search(r"(\d+)", d.get("sclk clock speed:", ""))
+                pw = next((float(v) for k_, v in d.items() if "Power (W)" in k_), None)
+                if clk and pw is not None:
+                    samples.append((int(clk.group(1)), pw))
+            except Exception:          # noqa: BLE001 -- a diagnostic: never fail the bench over it
+                return
+            time.sleep(0.3)
+    th = threading.Thread(target=sampler, daemon=True)
+    t_end = time.perf_counter() + seconds
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize(dev)
+    th.start()
+    while time.perf_counter() < t_end or th.is_alive():
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize(dev)
+        if time.perf_counter() > t_end + 6.0:
+            break
+    th.join(timeout=1.0)
+    if not samples:
+        return None
+    return {"sclk_mhz": sorted(c for c, _ in samples)[len(samples) // 2], "package_power_w": sorted(p_ for _, p_ in samples)[len(samples) // 2],
+            "samples": len(samples), "nominal_sclk_mhz": 2400, "package_power_cap_w": 1400,
+            "note": "median of rocm-smi samples while the timed step runs back to back"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -546,8 +587,9 @@ def main():
 
     # batch-1 latency: the only way the reference ever calls the model (/root/reference/demo/demo_match.py:29,
     # balf/utils/train_utils.py:428) -- one uint8 image in, keypoints out, a synchronisation per call
-    latency = None
+    latency = power = None
     if world == 1 and args.other_configs and (h, w, b) == (1080, 1920, 32):
+        power = power_state_under_load(step, dev)
         latency = [single_image_latency(model, dev, hh, ww, kk) for (hh, ww, kk) in ((480, 640, 1000), (1080, 1920, 2000))]
 
     if rank == 0:
@@ -585,6 +627,7 @@ def main():
             "other_precision": other,
             "other_configs": other_cfgs,
             "batch1_latency": latency,
+            "power_state_under_load": power,
         }
         if world == 1 and args.cpu_images > 0:
             n = min(args.cpu_images, b)
