@@ -3,6 +3,7 @@
 // alone.  Each mode runs one instruction stream on every SIMD (2 waves per SIMD, as the stage kernels) for a few seconds
 // while tools/power_probe.sh samples rocm-smi; the program prints the achieved instruction rate.
 //   mode 0: v_mfma_f32_16x16x32_f16   1: v_mfma_f32_32x32x16_f16   2: v_fma_f32   3: v_exp_f32   4: 1 MFMA(16x16x32) : 6 fma
+//   5: v_pk_fma_f32   6: the operand split of a pair
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/power_probe.hip -o tools/ubench/power_probe
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(512) void k(float *out, int iters) {
             s = s * 1664525u + 1013904223u; hb[v][i] = (_Float16)(((int)(s >> 20) - 2048) * 0.0007f);
         }
     const float m = 0.9991f, c = 0.0013f;
+    const float pm[2] = {m, m}, pc[2] = {c, c};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -40,6 +42,21 @@ __global__ __launch_bounds__(512) void k(float *out, int iters) {
             if (MODE == 3)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+            if (MODE == 5)          // 16 fp32 FMAs as eight packed instructions on register pairs
+#pragma unroll
+                for (int i = 0; i < 16; i += 2)
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(*reinterpret_cast<double *>(&a[i])) : "v"(*reinterpret_cast<const double *>(&pm[0])), "v"(*reinterpret_cast<const double *>(&pc[0])));
+            if (MODE == 6)          // the operand split of one pair: v_cvt_pkrtz + 2 v_fma_mix_f32 + v_cvt_pkrtz, four pairs
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    unsigned hh;
+                    asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(hh) : "v"(a[i]), "v"(a[i + 1]));
+                    float r0 = a[i], r1 = a[i + 1];
+                    asm volatile("v_fma_mix_f32 %0, %2, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, -1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r0), "+v"(r1) : "v"(hh));
+                    unsigned ll;
+                    asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(ll) : "v"(r0), "v"(r1));
+                    a[i] += __builtin_bit_cast(float, (hh & 0x3fff3fffu)) * 1e-30f; a[i + 1] += __builtin_bit_cast(float, (ll & 0x3fff3fffu)) * 1e-30f;
+                }
             if (MODE == 4)
 #pragma unroll
                 for (int i = 0; i < 6; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[(j * 6 + i) & 15]) : "v"(m), "v"(c));
@@ -64,6 +81,8 @@ int main(int argc, char **argv) {
             case 1: hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, out, iters); break;
             case 2: hipLaunchKernelGGL(k<2>, dim3(256), dim3(512), 0, 0, out, iters); break;
             case 3: hipLaunchKernelGGL(k<3>, dim3(256), dim3(512), 0, 0, out, iters); break;
+            case 5: hipLaunchKernelGGL(k<5>, dim3(256), dim3(512), 0, 0, out, iters); break;
+            case 6: hipLaunchKernelGGL(k<6>, dim3(256), dim3(512), 0, 0, out, iters); break;
             default: hipLaunchKernelGGL(k<4>, dim3(256), dim3(512), 0, 0, out, iters); break;
         }
     };
@@ -79,9 +98,9 @@ int main(int argc, char **argv) {
         el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } while (el < secs);
     // per iteration and wave: 8 MFMA(16x16x32) | 4 MFMA(32x32x16) | 128 fma | 32 exp | 8 MFMA + 48 fma;  2048 waves
-    const double per_iter[5] = {8, 4, 128, 32, 8};
+    const double per_iter[7] = {8, 4, 128, 32, 8, 64, 32};
     const double rate = n * (double)iters * per_iter[mode] * 2048 / el;
-    const char *what[5] = {"MFMA16x16x32", "MFMA32x32x16", "v_fma_f32", "v_exp_f32", "MFMA16x16x32 (+6 fma each)"};
+    const char *what[7] = {"MFMA16x16x32", "MFMA32x32x16", "v_fma_f32", "v_exp_f32", "MFMA16x16x32 (+6 fma each)", "v_pk_fma_f32", "operand-split pairs (4 instr + 2 adds each)"};
     printf("mode %d: %.3e %s wave-instructions/s over %.1f s (%.2f per SIMD per us)\n", mode, rate, what[mode], el, rate / 1024 / 1e6);
     return 0;
 }
