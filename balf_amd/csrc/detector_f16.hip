@@ -141,7 +141,13 @@ __device__ __forceinline__ void gemm16(f4 (&acc)[NTT][P], const float *w, int wn
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, never for its loads or stores (__syncthreads() emits
 // vmcnt(0)).  ONE asm statement with a memory clobber: the raw s_barrier builtin is IntrNoMem, so the compiler could
 // otherwise move LDS accesses across it.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifndef BALF_ABLATE_BARRIER
+#define BALF_ABLATE_BARRIER 0     // timing experiment: no workgroup barriers in the channel-split kernels (wrong results)
+#endif
+__device__ __forceinline__ void lds_barrier() {
+    if (BALF_ABLATE_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 #ifndef BALF_STAMPS
 #define BALF_STAMPS 0

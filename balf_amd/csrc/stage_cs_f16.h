@@ -111,6 +111,9 @@ __device__ __forceinline__ void cs_gelu(f4 (&t)[2][4]) {
         }
 }
 
+#ifndef BALF_ABLATE_LUTCOPY
+#define BALF_ABLATE_LUTCOPY 0   // timing experiment: the GELU table is not copied into LDS (wrong results)
+#endif
 #ifndef BALF_CS_SCHED
 #define BALF_CS_SCHED 1      // 1: a scheduling fence only behind the weight requests (measured best; 0: none, 2: also behind the MFMAs)
 #endif
@@ -317,7 +320,9 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
             const int fi = 2 * wave + f, kk = fi >> 2, p = fi & 3;
             xin[f] = load_frag_px(A.X, pix0 + p * pstep, CIN, kk, q);
         }
-        if constexpr (cs_gelu_lut<MODE>()) {     // GELU chord table -> LDS offset 0 (published by the barrier below)
+        if constexpr (cs_gelu_lut<MODE>() && !BALF_ABLATE_LUTCOPY) {     // GELU chord table -> LDS offset 0 (published by the barrier below)
+            // (requesting all of a thread's chunks before the first store -- one L2 round trip instead of four -- measured
+            // SLOWER: the C = 64 grid kernel 1.05 -> 1.15 ms)
             for (int i = threadIdx.x; i < cs_lut_bytes<MODE>() / 16; i += NW * G * 64)
                 *reinterpret_cast<uint4 *>(smem_all + i * 16) = *reinterpret_cast<const uint4 *>(bb + (size_t)kLayout.gelu_log * 4 + i * 16);
         }
