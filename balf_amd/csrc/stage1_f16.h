@@ -394,7 +394,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     // schedule's stride (two integer divisions per group would cost ~80 scalar instructions each)
     struct Pos { int n, gy, gx; };
     struct Geo { int n, y, x0; long pix0; };
-    const int ty = n >> 2, tx0 = 2 * (n & 3);
+    const int ty_ = n >> 2, tx0_ = 2 * (n & 3);
     const int pstep = (MODE == 0) ? fw : 1;
     auto decompose = [&](int i) {
         Pos c;
@@ -412,6 +412,15 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     auto geo = [&](const Pos &c) {
         Geo g;
         g.n = c.n;
+        int ty = ty_, tx0 = tx0_;
+        if constexpr (MODE == 2) {
+            // (tail, three waves per SIMD = 168 registers: two instructions per group instead of two registers held across
+            // the loop -- hipcc otherwise spills one of them and reloads it from scratch in every iteration)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            ty = (ln & 31) >> 2;
+            tx0 = 2 * (ln & 3);
+        }
         if (MODE == 0) { g.y = ty * fh + c.gy; g.x0 = tx0 * fw + c.gx; }
         else           { g.y = 8 * c.gy + ty;  g.x0 = 8 * c.gx + tx0; }
         g.pix0 = ((long)g.n * H + g.y) * W + g.x0;
@@ -566,10 +575,6 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             f16v t[2];
             s1_bias(t, par + kS1pR2B, h);
             s1_linear<2>(t, wl + kS1R2, b);
-            // (the image's SE scale is requested here, not at the top: 16 registers less through the branch -- at three waves
-            // per SIMD the kernel otherwise spills; an L2 hit that conv0 covers)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) sct[gq] = *reinterpret_cast<const f4 *>(A.scale + (long)g.n * C + 8 * gq + 4 * h);
             // the raw pixels likewise (plain loads; the tail has no prefetch across groups)
             if constexpr (U8) load_raw_u8(g, raw);
             else {
@@ -581,37 +586,66 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
             make_bx();
             f16v x0v[2];
             conv0(x0v);
+            // r = x1 + x0 first (x1's 32 registers die here), then the image's SE scale -- requested here, not at the top: at
+            // three waves per SIMD the kernel otherwise spills; an L2 hit that the other waves cover
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x0v[p][r] = x1t[p][r] + x0v[p][r];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) sct[gq] = *reinterpret_cast<const f4 *>(A.scale + (long)g.n * C + 8 * gq + 4 * h);
             // v = r + s t with r = x1 + x0, max over the 2x2 window: the lane's two tiles are horizontal neighbours, the
-            // rows 2 j, 2 j + 1 sit in lanes n, n + 4 (DPP row_shl:4 brings lane n + 4 to lane n: used where n & 4 == 0)
+            // rows 2 j, 2 j + 1 sit in lanes n, n + 4
             f16v mx;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float sc = sct[r >> 2][r & 3];
-                const float v0 = fmaf(t[0][r], sc, x1t[0][r] + x0v[0][r]);
-                const float v1 = fmaf(t[1][r], sc, x1t[1][r] + x0v[1][r]);
+                const float v0 = fmaf(t[0][r], sc, x0v[0][r]);
+                const float v1 = fmaf(t[1][r], sc, x0v[1][r]);
                 const float m = __builtin_fmaxf(v0, v1);
-                const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                    0, __builtin_bit_cast(int, m), 0x104 /* row_shl:4 */, 0xF, 0xF, false));
-                mx[r] = __builtin_fmaxf(m, o);
+                // the vertical partner's value in EVERY lane: lane n + 4's by row_shl:4, then -- into lane banks 1 and 3 only
+                // (bank_mask 0xA) -- lane n - 4's by row_shr:4.  (A first form copied the finished maximum from lane n to
+                // lane n + 4 with update_dpp(old = x, src = x): hipcc treated the sixteen results as one value and deleted
+                // fifteen of the sixteen maxima -- caught only because the wide-range test does not fall back to fp32.)
+                const int mi = __builtin_bit_cast(int, m);
+                const int up = __builtin_amdgcn_update_dpp(0, mi, 0x104 /* row_shl:4 */, 0xF, 0xF, false);
+                const int pv = __builtin_amdgcn_update_dpp(up, mi, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+                mx[r] = __builtin_fmaxf(m, __builtin_bit_cast(float, pv));
             }
-            if ((n & 4) == 0) {                                  // this lane holds pooled pixel (ty / 2, n & 3) of the 4 x 4 output block
+            // lanes n and n + 4 (n & 4 == 0) both hold pooled pixel (ty / 2, n & 3) of the 4 x 4 output block, so the FOUR lanes
+            // of a pooled pixel -- two lane halves x two partners -- store its 128-byte row as two instructions of 64
+            // contiguous bytes each (hi, lo), like the four lane quarters of the 16x16 layout did.  (Stored by the lanes n
+            // alone -- four 16-byte pieces each, 32 contiguous bytes per pixel and instruction -- the stage-2 grid kernel that
+            // reads this tensor next ran 5 % slower.)
+            {
                 const long opix = ((long)g.n * (H / 2) + (g.y >> 1)) * (W / 2) + (g.x0 >> 1);
                 const HL s0 = s1_split8(mx, 0), s1 = s1_split8(mx, 1);
+                const int part = (n >> 2) & 1;                   // 0: the lane n of the pair, 1: its partner n + 4
+                const unsigned pm = 0u - (unsigned)part;
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                auto pick = [&](const h8 &a, const h8 &b) {     // partner ? b : a, one v_bfi per register
+                    const u4 ua = __builtin_bit_cast(u4, a), ub = __builtin_bit_cast(u4, b);
+                    u4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (ub[i] & pm) | (ua[i] & ~pm);
+                    return __builtin_bit_cast(h8, o);
+                };
                 if constexpr (NEXT32) {
-                    store_frag32(A.out, opix, C, 0, h, s0);
-                    store_frag32(A.out, opix, C, 1, h, s1);
+                    // 32x32 fragment format: K-step s at + 64 s: [hi: h0, h1][lo: h0, h1]; lane n stores K-step 0, its partner K-step 1
+                    const HL v{pick(s0.hi, s1.hi), pick(s0.lo, s1.lo)};
+                    store_frag32(A.out, opix, C, part, h, v);
                 } else {
                     // 16x16 fragment format: lane quarter q's 16 bytes are channels 4 q + (0..3) and 16 + 4 q + (0..3); this
-                    // lane holds channels 8 g + 4 h + (0..3): quarter h <- (g = 0, g = 2), quarter 2 + h <- (g = 1, g = 3)
+                    // lane holds channels 8 g + 4 h + (0..3): quarter h <- (g = 0, g = 2), quarter 2 + h <- (g = 1, g = 3);
+                    // lane n stores quarter h, its partner quarter 2 + h
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                     auto lo4 = [](const h8 &v) { return h4{v[0], v[1], v[2], v[3]}; };
                     auto hi4 = [](const h8 &v) { return h4{v[4], v[5], v[6], v[7]}; };
                     auto cat = [](const h4 &a, const h4 &c) { return h8{a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]}; };
-                    char *op = reinterpret_cast<char *>(A.out) + opix * (long)C * 4;
-                    *reinterpret_cast<h8 *>(op + h * 16) = cat(lo4(s0.hi), lo4(s1.hi));
-                    *reinterpret_cast<h8 *>(op + (2 + h) * 16) = cat(hi4(s0.hi), hi4(s1.hi));
-                    *reinterpret_cast<h8 *>(op + 64 + h * 16) = cat(lo4(s0.lo), lo4(s1.lo));
-                    *reinterpret_cast<h8 *>(op + 64 + (2 + h) * 16) = cat(hi4(s0.lo), hi4(s1.lo));
+                    char *op = reinterpret_cast<char *>(A.out) + opix * (long)C * 4 + (h + 2 * part) * 16;
+                    *reinterpret_cast<h8 *>(op) = pick(cat(lo4(s0.hi), lo4(s1.hi)), cat(hi4(s0.hi), hi4(s1.hi)));
+                    *reinterpret_cast<h8 *>(op + 64) = pick(cat(lo4(s0.lo), lo4(s1.lo)), cat(hi4(s0.lo), hi4(s1.lo)));
                 }
             }
         } else {
