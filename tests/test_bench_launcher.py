@@ -40,6 +40,16 @@ def test_plain_gpus2_starts_two_ranks():
     assert res["per_rank_images_per_s"]["min"] <= res["per_rank_images_per_s"]["max"]
 
 
+def test_plain_gpus8_starts_eight_ranks():
+    """the node size the driver's scaling run ends with (N = 8): eight ranks, one line, global batch 8 x per-rank batch"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8"] + STUB, env=_env(OMP_NUM_THREADS="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _one_line(r.stdout)
+    assert res["n_gpus"] == 8 and res["rccl_ranks"] == 8 and res["config"]["global_batch"] == 32
+    assert res["config"]["parallelism"] == "dp8" and res["scaling"] == "weak"
+
+
 def test_torchrun_form_gives_the_same_line():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2"] + STUB,
