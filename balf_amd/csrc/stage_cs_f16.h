@@ -320,9 +320,10 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
             const int fi = 2 * wave + f, kk = fi >> 2, p = fi & 3;
             xin[f] = load_frag_px(A.X, pix0 + p * pstep, CIN, kk, q);
         }
+        STAMPV(17);  // (diagnostic) kernel entry -> geometry and the input loads issued
         if constexpr (cs_gelu_lut<MODE>() && !BALF_ABLATE_LUTCOPY) {     // GELU chord table -> LDS offset 0 (published by the barrier below)
-            // (requesting all of a thread's chunks before the first store -- one L2 round trip instead of four -- measured
-            // SLOWER: the C = 64 grid kernel 1.05 -> 1.15 ms)
+            // (the phase stamps show ~6 k cycles here at C = 64: that is the strided input gather's HBM latency, which these
+            // loads queue behind -- requesting all of a thread's chunks before the first store changes nothing)
             for (int i = threadIdx.x; i < cs_lut_bytes<MODE>() / 16; i += NW * G * 64)
                 *reinterpret_cast<uint4 *>(smem_all + i * 16) = *reinterpret_cast<const uint4 *>(bb + (size_t)kLayout.gelu_log * 4 + i * 16);
         }
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
                     *reinterpret_cast<const uint4 *>(bb + (size_t)Br.mix_w * 4 + stile * 2048 + part * 1024 + sl * 16);
             }
         }
+        STAMPV(18);  // (diagnostic) GELU table / mixing matrix copied
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             const int fi = 2 * wave + f;
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
             bxin[(fi * 2 + 1) * 64 + lane] = xin[f].lo;
         }
     }
+    STAMPV(19);  // (diagnostic) input fragments arrived and written to LDS
     if constexpr (!TAIL) barrier();                            // (tail: conv0 runs last, behind the barriers of the RCAB branch)
     STAMPV(1);   // input staged
 

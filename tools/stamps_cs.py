@@ -27,7 +27,8 @@ for kid in range(2, 8):
     v = [sums[kid * NS + i] / n for i in range(NS)]
     tot = sum(v[1:len(names)])
     print(f"C={[32,64,128,256][kid//2]} {'block' if kid%2 else 'grid'}: {n} groups, {tot:8.0f} cycles/group:  " +
-          "  ".join(f"{names[i]}={v[i]:.0f}" for i in range(1, len(names)) if v[i]))
+          "  ".join(f"{names[i]}={v[i]:.0f}" for i in range(1, len(names)) if v[i]) +
+          f"  || start-up detail: issued={v[17]:.0f} table={v[18]:.0f} arrived={v[19]:.0f} barrier={v[1]:.0f}")
 for kid in range(2, 8):
     if cnt[kid]:
         print(f"kid {kid}: SIMD of wave slot w (rows) : " + " | ".join(" ".join(str(sums[(8 + kid) * NS + w * 4 + sd]) for sd in range(4)) for w in range(8)))
