@@ -1,5 +1,5 @@
-"""Per-phase cycle breakdown of the channel-split stage kernels (diagnostic build libbalf_hip_stamps.so: -DBALF_STAMPS=1
--DBALF_S1_WAVE=0): wave 0 of every workgroup stamps s_memtime between the phases of its token group (the STAMPV(i) points of
+"""Per-phase cycle breakdown of the channel-split stage kernels (diagnostic build: tools/build_variant.sh stamps -DBALF_STAMPS=1
+-> balf_amd/libbalf_hip_stamps.so): wave 0 of every workgroup stamps s_memtime between the phases of its token group (the STAMPV(i) points of
 stage_cs_f16.h, kept in a register per lane: no memory traffic between stamps), and every wave records the SIMD it runs on."""
 import ctypes as C, os, sys
 import torch
