@@ -1,4 +1,4 @@
-"""Per-phase cycle breakdown of the persistent stage-1 kernels (diagnostic build libbalf_hip_stamps.so, -DBALF_STAMPS=1):
+"""Per-phase cycle breakdown of the persistent stage-1 kernels (diagnostic build: tools/build_variant.sh stamps -DBALF_STAMPS=1):
 wave 0 of every workgroup stamps s_memtime between the phases of every token group it processes."""
 import ctypes as C, os, sys
 import torch
@@ -11,7 +11,8 @@ m = get_model.load_model(arch.DEFAULT_MODEL_CFG); m.load_state_dict(synth.synthe
 m = m.eval().cuda()
 x = torch.rand((8, 3, 1088, 1920), device="cuda")
 raw = C.CDLL(os.environ["BALF_HIP_LIB"])
-sums = (C.c_ulonglong * (16 * 24))(); cnt = (C.c_ulonglong * 16)()
+NS = 40                                    # g_stamp_sum[16][40] (detector_f16.hip)
+sums = (C.c_ulonglong * (16 * NS))(); cnt = (C.c_ulonglong * 16)()
 m(x, want_logits=False); torch.cuda.synchronize()
 raw.balf_debug_stamps(sums, cnt, 1)
 for _ in range(2): m(x, want_logits=False)
@@ -19,11 +20,11 @@ torch.cuda.synchronize()
 raw.balf_debug_stamps(sums, cnt, 0)
 names = {0: ["", "input", "conv0+LN", "q1+GELU", "LN+split", "d1a+GELU", "d1b+GELU+LN+bT", "mix+gate", "d2+res", "U store"],
          1: ["", "input", "conv0+LN", "q1+GELU", "LN+split", "d1a+GELU", "d1b+GELU+LN+bT", "mix+gate", "d2+res", "q2(u',v')",
-             "conv0+R store", "LN+r1+lrelu", "r2+T store+sums"]}
+             "residuals+x1 store", "LN+r1+lrelu", "channel sums"]}
 for kid in (0, 1):
     n = cnt[kid]
     if not n: continue
     nm = names[kid]
-    tot = sum(sums[kid * 24 + i] for i in range(1, len(nm)))
+    tot = sum(sums[kid * NS + i] for i in range(1, len(nm)))
     print(f"stage1 {'block' if kid else 'grid'}: {n} groups stamped, {tot/n:8.0f} cycles/group:  " +
-          "  ".join(f"{nm[i]}={sums[kid*24+i]/n:.0f}" for i in range(1, len(nm))))
+          "  ".join(f"{nm[i]}={sums[kid*NS+i]/n:.0f}" for i in range(1, len(nm))))
