@@ -22,6 +22,7 @@ PROTOTYPES = {
     "balf_abi_version": (_i, []),
     "balf_error_string": (C.c_char_p, [_i]),
     "balf_device_check": (_i, []),
+    "balf_build_flags": (C.c_char_p, []),
     "balf_num_state_tensors": (_i, []),
     "balf_state_tensor_name": (C.c_char_p, [_i]),
     "balf_state_tensor_numel": (_sz, [_i]),
@@ -88,6 +89,13 @@ def lib() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         if l.balf_abi_version() != 1:
             raise BalfHipError("libbalf_hip.so ABI version mismatch")
+        flags = l.balf_build_flags().decode()
+        if not flags.startswith("release"):
+            # a timing-ablation / instrumented build (csrc/diag.h) computes wrong results: only ever loaded on purpose
+            if "BALF_HIP_LIB" not in os.environ:
+                raise BalfHipError(f"{LIB_PATH} is a diagnostic build ({flags}): rebuild it with balf_amd/csrc/build.sh")
+            import warnings
+            warnings.warn(f"balf_amd: {LIB_PATH} is a DIAGNOSTIC build ({flags}); its results are not valid", RuntimeWarning)
         _lib = l
     return _lib
 

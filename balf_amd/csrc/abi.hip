@@ -1,5 +1,6 @@
 // Library-level entry points of libbalf_hip.so (version, error strings, device check).
 #include "common.h"
+#include "diag.h"
 
 #include <string.h>
 
@@ -23,4 +24,13 @@ extern "C" int balf_device_check(void) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) != hipSuccess) return BALF_ERR_ARCH;
     return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? BALF_OK : BALF_ERR_ARCH;
+}
+
+// What kind of build this is (csrc/diag.h): "release ..." when every diagnostic switch is off.
+extern "C" const char *balf_build_flags(void) {
+#if BALF_DIAGNOSTIC_BUILD
+    return "DIAGNOSTIC" BALF_DIAG_FLAGS_STRING;
+#else
+    return "release" BALF_DIAG_FLAGS_STRING;
+#endif
 }

@@ -17,7 +17,9 @@ for f in *.hip; do
     pids+=($!)
   fi
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+fail=0
+for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || fail=1; }; done
+[ $fail = 0 ] || { echo "build.sh: a translation unit failed to compile" >&2; exit 1; }
 $HIPCC --offload-arch=gfx950 -shared -fPIC obj/*.o -o ../libbalf_hip.so
 # the hand-counted waits of stage1_f16.h are checked against the built code (tests/test_build_invariants.py); the compiler that
 # produced it is recorded next to the library so that a toolchain change is visible

@@ -2,6 +2,7 @@
 // split-f16 (detector_f16.hip) implementations of the detector forward.
 #pragma once
 #include "common.h"
+#include "diag.h"
 #include "layout.h"
 #include "prof.h"
 
@@ -127,9 +128,6 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
 #endif
 }
 
-#ifndef BALF_ABLATE_GELU
-#define BALF_ABLATE_GELU 0
-#endif
 // PACKED: 2-wide vector math (v_pk_*): fewer VALU slots, but the register pairs it needs cost more than they
 // save in the register-starved kernels (block branch, C = 256) -- measured per kernel, see DESIGN.md.
 // AS: the longer Abramowitz-Stegun form -- kept for the 128-register N-split kernel of stage 3, which spills 35 registers

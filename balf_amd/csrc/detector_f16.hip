@@ -43,9 +43,6 @@ __device__ __forceinline__ HL split8(const f4 &t0, const f4 &t1) {
 }
 
 // pre-split activation row in HBM ("fragment format"): pixel base + ks*128 + {0: hi, 64: lo} + q*16 bytes
-#ifndef BALF_ABLATE_LOADLAT
-#define BALF_ABLATE_LOADLAT 0     // timing experiment: activation rows come from a small L2-resident window (wrong results)
-#endif
 __device__ __forceinline__ HL load_frag_px(const float *base, long pix, int C, int ks, int q) {
     if (BALF_ABLATE_LOADLAT) pix &= 4095;
     const char *p = reinterpret_cast<const char *>(base) + pix * (long)C * 4 + ks * 128 + q * 16;
@@ -141,17 +138,11 @@ __device__ __forceinline__ void gemm16(f4 (&acc)[NTT][P], const float *w, int wn
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, never for its loads or stores (__syncthreads() emits
 // vmcnt(0)).  ONE asm statement with a memory clobber: the raw s_barrier builtin is IntrNoMem, so the compiler could
 // otherwise move LDS accesses across it.
-#ifndef BALF_ABLATE_BARRIER
-#define BALF_ABLATE_BARRIER 0     // timing experiment: no workgroup barriers in the channel-split kernels (wrong results)
-#endif
 __device__ __forceinline__ void lds_barrier() {
     if (BALF_ABLATE_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-#ifndef BALF_STAMPS
-#define BALF_STAMPS 0
-#endif
 #if BALF_STAMPS
 __device__ unsigned long long g_stamp_sum[16][40];
 __device__ unsigned long long g_stamp_cnt[16];

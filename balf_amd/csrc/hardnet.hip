@@ -94,9 +94,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // In-kernel stamps (diagnostic build -DBALF_HN_STAMPS=1 only): thread 0 of every workgroup adds the cycles between
 // consecutive HSTAMP(i) points to g_hn_stamp[kernel][i]; balf_debug_hn_stamps() reads them back (tools/hn_stamps.py).
-#ifndef BALF_HN_STAMPS
-#define BALF_HN_STAMPS 0
-#endif
 #if BALF_HN_STAMPS
 __device__ unsigned long long g_hn_stamp[8][8];
 #define HSTAMP_DECL unsigned long long hs_prev = 0; (void)hs_prev

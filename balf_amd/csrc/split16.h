@@ -12,6 +12,7 @@
 // exercises activations up to ~1e4 and the out-of-range failure).
 #pragma once
 #include "common.h"
+#include "diag.h"
 
 namespace balf {
 
@@ -28,18 +29,12 @@ __device__ __forceinline__ f4x mfma16(h8 a, h8 b, f4x c) {
 }
 
 // three-product accumulate: (ah + al)(bh + bl) ~ ah bh + al bh + ah bl
-#ifndef BALF_DROP_WLO
-#define BALF_DROP_WLO 0      // accuracy experiment: drop the (weight lo) x (activation hi) product of every Linear
-#endif
 __device__ __forceinline__ f4x mfma16x3(const HL &a, const HL &b, f4x c) {
     c = mfma16(a.lo, b.hi, c);
     c = mfma16(a.hi, b.lo, c);
     return mfma16(a.hi, b.hi, c);
 }
 
-#ifndef BALF_ABLATE_SPLIT
-#define BALF_ABLATE_SPLIT 0
-#endif
 #ifndef BALF_SPLIT_MIX
 #define BALF_SPLIT_MIX 1
 #endif

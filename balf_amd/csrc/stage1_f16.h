@@ -309,9 +309,6 @@ __device__ __forceinline__ void store_frag32(float *base, long pix, int C, int s
 #ifndef BALF_S1_KEEP_X0
 #define BALF_S1_KEEP_X0 1    // block kernel: keep x0 in registers (32) instead of recomputing it: -5 %
 #endif
-#ifndef BALF_S1_STRICT
-#define BALF_S1_STRICT 0     // 1: every hand-placed wait drains the queue (debugging aid)
-#endif
 #if BALF_S1_STRICT
 #define BALF_S1_WAIT_IN "s_waitcnt vmcnt(0)"
 #define BALF_S1_WAIT_U "s_waitcnt vmcnt(0)"

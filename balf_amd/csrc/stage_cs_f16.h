@@ -111,9 +111,6 @@ __device__ __forceinline__ void cs_gelu(f4 (&t)[2][4]) {
         }
 }
 
-#ifndef BALF_ABLATE_LUTCOPY
-#define BALF_ABLATE_LUTCOPY 0   // timing experiment: the GELU table is not copied into LDS (wrong results)
-#endif
 #ifndef BALF_CS_SCHED
 #define BALF_CS_SCHED 1      // 1: a scheduling fence only behind the weight requests (measured best; 0: none, 2: also behind the MFMAs)
 #endif
@@ -134,7 +131,7 @@ struct CsBlob {
         return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, loff, off, 0));
     }
     __device__ __forceinline__ h8 frag(unsigned off) const {
-#if defined(BALF_ABLATE_WSTREAM) && BALF_ABLATE_WSTREAM
+#if BALF_ABLATE_WSTREAM
         off &= 1023u;                                         // timing experiment: every weight tile is the same L1-resident KiB (wrong results)
 #endif
         return __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, loff, off, 0));

@@ -13,7 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import warnings
-from operator import attrgetter
+from operator import attrgetter, is_ as _IS
 
 import torch
 import torch.nn as nn
@@ -23,11 +23,17 @@ from .._lib import BalfHipError, check, lib
 
 # The packed-weight cache must notice every way a checkpoint can change under it, and a single-image call (the
 # reference's only calling pattern, /root/reference/demo/demo_match.py:29) must not pay for that: walking the 167 state
-# tensors through nn.Module.__getattr__ cost 130 us per forward.  So: (i) an epoch counter bumped by torch's global
-# registration hooks whenever ANY module gets a parameter or buffer (re)registered (assignment, load_state_dict(assign=True))
-# and by this module's _apply (.to(), .cuda(), .float(): buffers are replaced there), which invalidates the cached tensor
-# LIST; (ii) per call, the sum of the version counters of the cached tensors (in-place updates: load_state_dict, copy_,
-# optimiser steps), ~10 us.
+# tensors through nn.Module.__getattr__ cost 130 us per forward.  So the module keeps a LIST of its state tensors and the
+# dict slots they came from, and the per-call key is built from that list alone:
+#   (i)   identity of every slot's current content (`m._parameters[name] is cached`): catches what replaces a Parameter or
+#         buffer object without telling anyone -- `_apply` on a SUBMODULE (model.down1.float(), model.detector_head.to(..):
+#         buffers are re-bound in the dict directly), parameter assignment, load_state_dict(assign=True);
+#   (ii)  the sum of the tensors' version counters: in-place updates (load_state_dict, copy_, optimiser steps);
+#   (iii) the tuple of their data pointers: `p.data = other` (EMA swaps, torch.nn.utils.vector_to_parameters, `_apply` on
+#         parameters), which changes neither the object nor -- reliably -- its version.
+# A module-level epoch, bumped by torch's global registration hooks, only says WHEN the list may have gained or lost an
+# entry (register_parameter / register_buffer anywhere in the process); a rebuilt list that holds the same objects keeps the
+# cache (building another model must not repack this one).
 _EPOCH = [0]
 
 
@@ -38,6 +44,8 @@ def _bump_epoch(*_args, **_kwargs):
 nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
 nn.modules.module.register_module_buffer_registration_hook(_bump_epoch)
 _VERSION = attrgetter("_version")
+_DATA_PTR = torch.Tensor.data_ptr
+_GETITEM = dict.get                      # (a deleted slot reads None: "changed")
 
 
 class _Holder(nn.Module):
@@ -98,89 +106,127 @@ class MLP_MA_DECODER(nn.Module):
         head.dense = _linear(dims[4], a["cell_size"] ** 2 + 1)
         head.norm = nn.BatchNorm2d(a["cell_size"] ** 2 + 1)
         self.detector_head = head
-        self.precision = precision
-        self._tensors = None           # (epoch, the state tensors in state_dict order), see _state_tensors
-        self._packed = None            # (device blob, key) cache; rebuilt when parameters change
-        self._packed_key = None
-        self._fp16_checked = None      # key of the weights the split-f16 path was last validated for (see _check_fp16_range)
+        self.precision = precision     # the REQUESTED precision; see effective_precision for what the last forward ran
+        self._tensors = None           # (epoch, [tensors in state_dict order], their dicts, their names), see _state_tensors
+        self._gen = 0                  # bumped whenever the tensor list holds a different object
+        self._packed = {}              # precision -> (weights key, device blob)
+        self._fp16_verdict = None      # (weights key, precision the split-f16 request resolves to for these weights)
+        self._effective = None
 
     # ---- weights -> packed device blob -------------------------------------------------------
-    def _precision_code(self) -> int:
+    @staticmethod
+    def _code_of(precision) -> int:
         try:
-            return {"fp32": _lib.PREC_FP32, "fp16": _lib.PREC_FP16}[self.precision]
+            return {"fp32": _lib.PREC_FP32, "fp16": _lib.PREC_FP16}[precision]
         except KeyError:
-            raise ValueError(f"precision must be 'fp32' or 'fp16', got {self.precision!r}")
+            raise ValueError(f"precision must be 'fp32' or 'fp16', got {precision!r}")
+
+    def _precision_code(self) -> int:
+        return self._code_of(self.precision)
+
+    @property
+    def effective_precision(self) -> str:
+        """What the last forward actually ran: ``precision``, or 'fp32' after the split-f16 range check failed for the
+        weights loaded at that time (re-evaluated whenever the weights change)."""
+        return self._effective or self.precision
 
     def _apply(self, fn, *args, **kwargs):
-        _bump_epoch()                  # .to() / .cuda() / .float() replace buffers (and may replace parameters)
+        _bump_epoch()                  # (the slot check below notices this too; kept so that a move is never missed)
         return super()._apply(fn, *args, **kwargs)
 
     def _state_tensors(self):
-        """The 167 state tensors in state_dict order; the list is rebuilt only when a parameter or buffer was
-        (re)registered somewhere since (module-level epoch), in-place changes show in the version counters."""
-        if self._tensors is None or self._tensors[0] != _EPOCH[0]:
-            ts = [getattr(m, n) for m in self.modules() for n in
-                  list(m._parameters.keys()) + [b for b in m._buffers.keys() if b not in m._non_persistent_buffers_set]]
-            self._tensors = (_EPOCH[0], ts)
-        return self._tensors[1]
+        """The 167 state tensors in state_dict order.  The list is re-walked when a parameter or buffer was registered
+        somewhere since (module-level epoch) or when a slot no longer holds the cached object; the generation counter --
+        part of the cache key -- moves only if the walk found a different object."""
+        c = self._tensors
+        if c is not None and c[0] == _EPOCH[0] and all(map(_IS, map(_GETITEM, c[2], c[3]), c[1])):
+            return c[1]
+        dicts, names = [], []
+        for m in self.modules():
+            for n in m._parameters:
+                dicts.append(m._parameters)
+                names.append(n)
+            for n in m._buffers:
+                if n not in m._non_persistent_buffers_set:
+                    dicts.append(m._buffers)
+                    names.append(n)
+        ts = list(map(_GETITEM, dicts, names))
+        if c is None or len(ts) != len(c[1]) or not all(map(_IS, ts, c[1])):
+            self._gen += 1
+        self._tensors = (_EPOCH[0], ts, dicts, names)
+        return ts
 
-    def _state_key(self, device):
+    def _weights_key(self, device):
         ts = self._state_tensors()
         try:
             ver = sum(map(_VERSION, ts))
         except RuntimeError:           # inference tensors (a model moved under torch.inference_mode()) track no versions
-            ver = tuple(t.data_ptr() for t in ts)     # ... and cannot be modified in place
-        return (self._tensors[0], str(device), self.precision, ver)
+            ver = -1                   # ... and cannot be modified in place; replacing them shows in the pointers
+        return (self._gen, str(device), ver, tuple(map(_DATA_PTR, ts)))
 
-    def packed_weights(self, device) -> torch.Tensor:
-        key = self._state_key(device)
-        if self._packed is None or self._packed_key != key:
-            l = lib()
-            sd = self.state_dict()
-            n = l.balf_num_state_tensors()
-            host = []
-            for i in range(n):
-                name = l.balf_state_tensor_name(i).decode()
-                t = sd[name].detach().to("cpu", torch.float32).contiguous()
-                if t.numel() != l.balf_state_tensor_numel(i):
-                    raise BalfHipError(f"{name}: {t.numel()} elements, library expects {l.balf_state_tensor_numel(i)}")
-                host.append(t)
-            ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in host])
-            prec = self._precision_code()
-            nbytes = l.balf_packed_weights_bytes(prec)
-            if nbytes == 0:
-                raise BalfHipError(f"precision {self.precision!r} is not available in this build of libbalf_hip.so")
-            blob = torch.empty(nbytes, dtype=torch.uint8)
-            check(l.balf_pack_weights(ptrs, n, prec, blob.data_ptr(), nbytes), "balf_pack_weights")
-            self._packed = blob.to(device)
-            self._packed_key = key
-            if self.precision == "fp16" and self._fp16_checked != key[:2] + key[3:]:
-                self._check_fp16_range(device, key)
-        return self._packed
+    def _state_key(self, device):
+        return self._weights_key(device) + (self.precision,)
 
-    def _check_fp16_range(self, device, key):
-        """Once per set of weights, when the split-f16 blob is (re)built: the default path carries every MFMA operand
-        as two f16 halves, and an activation or weight beyond +-6.5e4 turns into inf/NaN without any trap (split16.h).
-        A checkpoint is therefore tried on three small images (noise, black, white) against the exact-fp32 kernels; if the
-        score maps disagree or are not finite the module switches itself to ``precision='fp32'`` (still the HIP
-        library, ~2.5x slower) and says so -- or raises with BALF_FP16_STRICT=1."""
-        self._fp16_checked = key[:2] + key[3:]
-        if os.environ.get("BALF_FP16_CHECK", "1") == "0" or getattr(self, "_validating", False):
-            return                     # switched off, or the caller is validate_fp16 itself (it reports on ITS input)
+    def packed_weights(self, device, precision=None, _wkey=None) -> torch.Tensor:
+        """The packed blob of the current weights for ``precision`` (default: the requested one) on ``device``."""
+        precision = precision or self.precision
+        prec = self._code_of(precision)
+        wkey = _wkey or self._weights_key(device)
+        hit = self._packed.get(precision)
+        if hit is not None and hit[0] == wkey:
+            return hit[1]
+        l = lib()
+        sd = self.state_dict()
+        n = l.balf_num_state_tensors()
+        host = []
+        for i in range(n):
+            name = l.balf_state_tensor_name(i).decode()
+            t = sd[name].detach().to("cpu", torch.float32).contiguous()
+            if t.numel() != l.balf_state_tensor_numel(i):
+                raise BalfHipError(f"{name}: {t.numel()} elements, library expects {l.balf_state_tensor_numel(i)}")
+            host.append(t)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in host])
+        nbytes = l.balf_packed_weights_bytes(prec)
+        if nbytes == 0:
+            raise BalfHipError(f"precision {precision!r} is not available in this build of libbalf_hip.so")
+        blob = torch.empty(nbytes, dtype=torch.uint8)
+        check(l.balf_pack_weights(ptrs, n, prec, blob.data_ptr(), nbytes), "balf_pack_weights")
+        blob = blob.to(device)
+        self._packed[precision] = (wkey, blob)
+        return blob
+
+    def _resolve(self, device):
+        """-> (precision to run, its blob).  Once per set of weights, when the split-f16 path is requested: the default
+        path carries every MFMA operand as two f16 halves, and an activation or weight beyond +-6.5e4 turns into inf/NaN
+        without any trap (split16.h).  A checkpoint is therefore tried on three small images (noise, black, white) against
+        the exact-fp32 kernels; if the score maps disagree or are not finite THESE WEIGHTS run on the fp32 kernels (still
+        the HIP library, ~2.5x slower) and the module says so -- or raises with BALF_FP16_STRICT=1.  The requested
+        precision is left alone: the next checkpoint is judged afresh."""
+        wkey = self._weights_key(device)
+        prec = self.precision
+        if prec == "fp16" and not getattr(self, "_validating", False) and os.environ.get("BALF_FP16_CHECK", "1") != "0":
+            v = self._fp16_verdict
+            if v is None or v[0] != wkey:
+                self._fp16_verdict = v = (wkey, self._check_fp16_range(device))
+            prec = v[1]
+        self._code_of(prec)
+        self._effective = prec
+        return prec, self.packed_weights(device, prec, wkey)
+
+    def _check_fp16_range(self, device) -> str:
         g = torch.Generator(device="cpu").manual_seed(1)
         x = torch.stack([torch.rand((3, 128, 128), generator=g), torch.zeros((3, 128, 128)), torch.ones((3, 128, 128))])
         was_training = self.training
         try:
             self.training = False
             self.validate_fp16(x.to(device))
+            return "fp16"
         except BalfHipError as e:
             if os.environ.get("BALF_FP16_STRICT") == "1":
                 raise
             warnings.warn(f"balf_amd: this checkpoint is outside the range of the split-f16 path ({e}); "
-                          "switching this model to precision='fp32' (exact-fp32 MFMA kernels)", RuntimeWarning)
-            self.precision = "fp32"
-            self._packed = None
-            self.packed_weights(device)
+                          "running it with the exact-fp32 MFMA kernels (effective_precision='fp32')", RuntimeWarning)
+            return "fp32"
         finally:
             self.training = was_training
 
@@ -200,13 +246,13 @@ class MLP_MA_DECODER(nn.Module):
         dev = x.device
         _lib.require_mi355x(dev)
         l = lib()
-        blob = self.packed_weights(dev)
+        prec, blob = self._resolve(dev)
         prob = torch.empty((b, h, w), dtype=torch.float32, device=dev)
         logits = torch.empty((b, 65, h // 8, w // 8), dtype=torch.float32, device=dev) if want_logits else None
         nbytes = l.balf_forward_workspace_bytes(b, h, w)
         ws = ops._workspace("forward", dev, nbytes)
         with torch.cuda.device(dev):
-            check(l.balf_forward(blob.data_ptr(), self._precision_code(), x.data_ptr(), b, h, w,
+            check(l.balf_forward(blob.data_ptr(), self._code_of(prec), x.data_ptr(), b, h, w,
                                  logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
                                  ws.numel(), _lib.current_stream_ptr(dev)), "balf_forward")
         return {"logits": logits, "prob": prob}
@@ -254,13 +300,13 @@ class MLP_MA_DECODER(nn.Module):
         dev = images.device
         _lib.require_mi355x(dev)
         l = lib()
-        blob = self.packed_weights(dev)
+        prec, blob = self._resolve(dev)
         prob = torch.empty((b, hp, wp), dtype=torch.float32, device=dev)
         logits = torch.empty((b, 65, hp // 8, wp // 8), dtype=torch.float32, device=dev) if want_logits else None
         nbytes = l.balf_forward_workspace_bytes(b, hp, wp)
         ws = ops._workspace("forward", dev, nbytes)
         with torch.cuda.device(dev):
-            check(l.balf_forward_u8(blob.data_ptr(), self._precision_code(), images.data_ptr(), ch, b, h, w,
+            check(l.balf_forward_u8(blob.data_ptr(), self._code_of(prec), images.data_ptr(), ch, b, h, w,
                                     logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
                                     ws.numel(), _lib.current_stream_ptr(dev)), "balf_forward_u8")
         return {"logits": logits, "prob": prob}

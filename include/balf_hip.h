@@ -53,6 +53,9 @@ int balf_abi_version(void);
 const char *balf_error_string(int code);
 /* BALF_OK iff the current HIP device is a gfx950 part. */
 int balf_device_check(void);
+/* "release BALF_ABLATE_GELU=0 ..." for the library as shipped; "DIAGNOSTIC ..." with the switch values when it was built
+ * with any of the timing-ablation / instrumentation switches of csrc/diag.h (wrong results: never to be deployed). */
+const char *balf_build_flags(void);
 
 /* ---- weights ------------------------------------------------------------------------------
  * The 166 floating-point state-dict tensors of MLP_MA_DECODER in state_dict() order

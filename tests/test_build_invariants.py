@@ -117,3 +117,98 @@ def test_no_inline_asm_valu_writes_fresh_register():
             if re.search(r'"=&?v"', outputs):
                 bad.append((name, text[:m.start()].count("\n") + 1, template.strip()[:60]))
     assert not bad, bad
+
+
+def _audit_module():
+    import importlib.util
+    for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"):
+        if not os.path.exists(os.path.join(LLVM, t)):
+            pytest.skip(f"{t} not available")
+    spec = importlib.util.spec_from_file_location(
+        "vmcnt_audit", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "vmcnt_audit.py"))
+    va = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(va)
+    return va
+
+
+def _regs(operand):
+    """'v7' -> {7}, 'v[8:9]' -> {8, 9}, anything else -> empty."""
+    m = re.fullmatch(r"v(\d+)", operand)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def test_shipped_library_is_a_release_build():
+    """the timing-ablation / instrumentation switches (csrc/diag.h: wrong results) must be provably off in the
+    library the tests and the bench load.  balf_build_flags() is compiled from the same macros the kernels see."""
+    flags = _lib.lib().balf_build_flags().decode()
+    assert flags.startswith("release "), flags
+    items = dict(kv.split("=") for kv in flags.split()[1:])
+    assert len(items) >= 10 and all(k.startswith("BALF_") for k in items), flags
+    assert all(v == "0" for v in items.values()), flags
+    for must in ("BALF_ABLATE_BARRIER", "BALF_ABLATE_LUTCOPY", "BALF_ABLATE_WSTREAM", "BALF_ABLATE_GELU", "BALF_DROP_WLO", "BALF_STAMPS"):
+        assert must in items, (must, flags)
+    # and the source keeps them in ONE place: no other header or translation unit defines such a switch
+    src = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".h", ".hip")) and name != "diag.h":
+            text = open(os.path.join(src, name)).read()
+            assert not re.search(r"#\s*define\s+(BALF_ABLATE_\w+|BALF_DROP_WLO|BALF_STAMPS|BALF_HN_STAMPS|BALF_S1_STRICT)\b", text), name
+
+
+def test_se_channel_sums_add_both_results_of_their_row_swap():
+    """DESIGN 4.3e mis-fold #1, as a code-object invariant.  The channel sums of the RCAB's hidden layer (stage1_f16.h, the
+    block kernel) add the TWO results of a v_permlane16_swap; hipcc once folded the second into the first -- the built code
+    read `v_pk_add_f32 v[8:9], v[0:1], v[0:1]`, the sums came out as 2 * sw[0] and the squeeze-excite scales a few per cent
+    off (inside the goldens' tolerance on the first run).  In the built block kernels every swap pair (vA, vB) must be consumed
+    by an add that reads BOTH registers, and no add may read one register as both of its sources."""
+    va = _audit_module()
+    kernels = va.disassemble(_lib.LIB_PATH, r"stage1_kernel16ILi1ELb[01]")
+    assert len(kernels) == 2, list(kernels)
+    for name, ins in kernels.items():
+        swaps = [(i, ops) for i, (_, mn, ops) in enumerate(ins) if mn and mn.startswith("v_permlane16_swap")]
+        assert len(swaps) == 8, (name, len(swaps))              # one per register pair (r, r + 8) of the 16-channel sums
+        for i, ops in swaps:
+            a, b = (_regs(o.strip()) for o in ops.split(","))
+            assert a and b and not (a & b), (name, ops)
+            for _, mn, o2 in ins[i + 1:i + 200]:
+                if not mn or not re.match(r"v_(pk_)?add_f32", mn):
+                    continue
+                srcs = [_regs(s.strip()) for s in o2.split(",")[1:3]]
+                if not any(a & s for s in srcs):
+                    continue
+                assert any(a & s for s in srcs) and any(b & s for s in srcs), (name, ops, mn, o2)
+                assert srcs[0] != srcs[1], (name, mn, o2)          # x + x: the mis-fold's signature
+                break
+            else:
+                raise AssertionError(f"{name}: no add consumes the swap {ops}")
+        for _, mn, o2 in ins:
+            if mn and re.match(r"v_(pk_)?add_f32", mn):
+                s = [t.strip() for t in o2.split(",")]
+                assert len(s) < 3 or s[1] != s[2] or not _regs(s[1]), (name, mn, o2)
+
+
+def test_tail_kernel_pools_sixteen_distinct_values():
+    """DESIGN 4.3e mis-fold #2.  The stage-1 tail kernel brings the vertical partner's maximum into every lane with two DPP
+    moves per accumulator register (row_shl:4, then row_shr:4 into lane banks 1 and 3); a first form let hipcc treat the
+    sixteen results as one value and delete fifteen of the sixteen maxima.  The built kernels must hold sixteen moves of
+    each kind, each reading a freshly computed value."""
+    va = _audit_module()
+    kernels = va.disassemble(_lib.LIB_PATH, r"stage1_kernel16ILi2ELb[01]")
+    assert len(kernels) == 2, list(kernels)
+    for name, ins in kernels.items():
+        for pat in (r"row_shl:4 row_mask:0xf bank_mask:0xf", r"row_shr:4 row_mask:0xf bank_mask:0xa"):
+            idx = [i for i, (_, mn, ops) in enumerate(ins) if mn == "v_mov_b32_dpp" and pat in ops]
+            assert len(idx) == 16, (name, pat, len(idx))
+            # sixteen different VALUES: identify what a move reads by the instruction that last wrote its source register
+            # (the compiler re-uses a few registers for the sixteen maxima)
+            defs = set()
+            for i in idx:
+                src = _regs(ins[i][2].split(",")[1].split()[0])
+                d = next((j for j in range(i - 1, -1, -1)
+                          if ins[j][1] and ins[j][2] and _regs(ins[j][2].split(",")[0].strip()) & src), None)
+                assert d is not None, (name, pat, i)
+                defs.add(d)
+            assert len(defs) == 16, (name, pat, sorted(defs))

@@ -281,7 +281,7 @@ def test_checkpoint_outside_f16_range_switches_to_fp32(monkeypatch):
     monkeypatch.delenv("BALF_FP16_STRICT", raising=False)            # (conftest sets it for every other test)
     with pytest.warns(RuntimeWarning, match="outside the range of the split-f16 path"):
         out = m(x)
-    assert m.precision == "fp32" and bool(torch.isfinite(out["prob"]).all())
+    assert m.precision == "fp16" and m.effective_precision == "fp32" and bool(torch.isfinite(out["prob"]).all())
     with torch.no_grad():
         ref = O.detector_forward(sd, x.cpu())["prob"].numpy()
     assert np.abs(out["prob"].cpu().numpy() - ref).max() < PROB_TOL
@@ -299,7 +299,14 @@ def test_checkpoint_outside_f16_range_switches_to_fp32(monkeypatch):
     with W.catch_warnings():
         W.simplefilter("error")
         m3(x)
-    assert m3.precision == "fp16"
+    assert m3.precision == "fp16" and m3.effective_precision == "fp16"
+    # the fallback belongs to the WEIGHTS, not to the module -- a well-scaled checkpoint loaded into the model
+    # that fell back runs on the split path again
+    m.load_state_dict(synth.synthetic_state_dict(cases.WEIGHT_SEED))
+    with W.catch_warnings():
+        W.simplefilter("error")
+        m(x)
+    assert m.effective_precision == "fp16"
 
 
 def test_workspace_cache_is_bounded_per_stream():

@@ -194,8 +194,10 @@ def test_repeatability_host_helpers_match_reference_golden():
 
 
 def test_packed_weight_cache_key_notices_every_kind_of_change():
-    """The per-call key of the packed-weight cache (a version sum over a cached tensor list + a registration epoch) must
-    change on in-place updates, load_state_dict (copy and assign), dtype / device moves and parameter replacement."""
+    """The per-call key of the packed-weight cache (slot identity + version sum + data pointers over a cached tensor list)
+    must change on in-place updates, load_state_dict (copy and assign), dtype / device moves of the model OR of a submodule,
+    parameter replacement, `p.data = ...` swaps and vector_to_parameters -- and must NOT change because some
+    other module was built or registered a parameter."""
     import torch
     from balf_amd import arch
     from balf_amd.model import get_model
@@ -220,6 +222,27 @@ def test_packed_weight_cache_key_notices_every_kind_of_change():
     assert m._state_tensors()[0] is m.down1.conv[0].weight
     m.double()
     changed()
+    m.float()
+    changed()
+    # the idioms the round-3 key missed
+    m.down2.conv2.weight.data = torch.ones(64, 64)                       # EMA-style swap
+    changed()
+    m.down1.double()                                                     # _apply on a submodule
+    changed()
+    m.detector_head.norm.double()                                        # ... one that owns buffers (re-bound in the dict)
+    changed()
+    assert m._state_tensors()[-3] is m.detector_head.norm.running_mean
+    m.float()
+    changed()
+    ps = list(m.down4.parameters())
+    torch.nn.utils.vector_to_parameters(torch.nn.utils.parameters_to_vector(ps) * 0 + 2.0, ps)
+    changed()
+    # other modules coming and going leave the key (and with it the packed blob and the f16 range verdict) alone
+    k = m._state_key("cpu")
+    other = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    torch.nn.Linear(3, 3).register_buffer("x", torch.zeros(1))
+    assert m._state_key("cpu") == k
+    del other
     m.precision = "fp32"
     changed()
     assert len(m._state_tensors()) == 167

@@ -5,7 +5,7 @@ name=$1; shift
 cd "$(dirname "$0")/../balf_amd/csrc"
 mkdir -p obj_$name
 for f in *.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c "$f" -o obj_$name/${f%.hip}.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DBALF_ALLOW_DIAGNOSTIC_BUILD=1 "$@" -c "$f" -o obj_$name/${f%.hip}.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC obj_$name/*.o -o ../libbalf_hip_$name.so
