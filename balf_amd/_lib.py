@@ -31,6 +31,8 @@ PROTOTYPES = {
     "balf_forward_workspace_bytes": (_sz, [_i, _i, _i]),
     "balf_forward": (_i, [_vp, _i, _fp, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
     "balf_forward_u8": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
+    "balf_forward_stage_view_numel": (_sz, [_i, _i, _i, _i]),
+    "balf_forward_stage_view": (_i, [_i, _vp, _sz, _i, _i, _i, _i, _fp, _vp]),
     "balf_window_nms": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp]),
     "balf_nms_topk_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "balf_nms_topk": (_i, [_fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _fp, _vp, _vp, _sz, _vp]),

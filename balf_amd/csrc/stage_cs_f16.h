@@ -1,21 +1,23 @@
-// Channel-split stage kernels for C >= 128 (split-f16 path).  Included by detector_f16.hip inside balf::{anonymous}.
+// Channel-split stage kernels of the split-f16 path: the grid branch, block branch and (C <= 128) tail kernels of every
+// stage that is not served by a persistent wave-owns-tokens kernel (stage1_f16.h) -- which stages those are is decided in
+// detector_f16.hip (run_stage16).  Included by detector_f16.hip inside balf::{anonymous}.
 //
 // Reference: Down.forward / ResidualSplitHeadMultiAxisGmlpLayer / {Grid,Block}GmlpLayer / RCAB of
-// /root/reference/balf/model/mlp_ma_decoder.py:25-149,173-244 at C = 128 / 256.
+// /root/reference/balf/model/mlp_ma_decoder.py:25-149,173-244 at C = 64 / 128 / 256.
 //
-// The weight-ring kernels above share every weight tile through LDS and pay for it with one workgroup barrier per ring
-// unit (86 / 157 per token group at C = 256), waves parked 43-47 % of the time and the LDS array busy 36-46 %.  Here the
-// workgroup splits every Linear by OUTPUT CHANNELS instead: wave w (of C/32) owns channels 32w .. 32w+31 of all 64
-// tokens of one token group -- a 2 x 4 register tile (two 16-channel row tiles x four 16-pixel tiles), the shapes of the
-// stage-1 kernel.  Consequences:
+// One workgroup = one token group (64 tokens); it splits every Linear by OUTPUT CHANNELS: wave w (of C/32) owns channels
+// 32w .. 32w+31 of all 64 tokens -- a 2 x 4 register tile (two 16-channel row tiles x four 16-pixel tiles) on
+// v_mfma_f32_16x16x32_f16.  Consequences:
 //   * a weight fragment is needed by exactly ONE wave: it comes straight from L2 into double-buffered registers (two
-//     K-steps ahead of the MFMAs), there is no ring, no LDS copy of the weights and no barrier per weight tile;
+//     K-steps ahead of the MFMAs), there is no LDS copy of the weights and no barrier per weight tile;
 //   * the 64x64 token mix of a channel is wave-local (transposed tile in wave-private LDS, as in stage 1);
 //   * what the waves exchange is the ACTIVATION: a Linear's input is the B operand of all waves, so every wave writes its
 //     32 channels as one K-step of split-f16 fragments into a shared buffer (64 KB at C = 256) and a barrier publishes
 //     it; LayerNorm needs the statistics of all channels of a pixel, exchanged through a small LDS table.  7 barriers per
 //     token group in the grid branch, 13 in the block branch.
-// Token t = 8 ty + tx of the group sits in MFMA column li of pixel tile p with t = 4 li + p (see stage1_f16.h).
+// (History: rounds 1-2 shared every weight tile through an LDS ring with one barrier per ring unit, 86 / 157 per token
+// group at C = 256; those kernels were removed in round 3.)
+// Token t = 8 ty + tx of the group sits in MFMA column li of pixel tile p with t = 4 li + p.
 #pragma once
 
 template <int C> constexpr int cs_waves() { return C / 32; }

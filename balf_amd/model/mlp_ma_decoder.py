@@ -257,6 +257,30 @@ class MLP_MA_DECODER(nn.Module):
                                  ws.numel(), _lib.current_stream_ptr(dev)), "balf_forward")
         return {"logits": logits, "prob": prob}
 
+    def stage_view(self, b: int, h: int, w: int, device=None):
+        """Validation aid: after ``forward`` / ``forward_u8`` of a batch whose PADDED shape is ``[b,3,h,w]`` on the current
+        stream, the activations that crossed the stage boundaries of that call, as fp32 NHWC tensors:
+        ``[down1 out, down2 out, down3 out, x2 of down4 before its conv2]`` (balf_forward_stage_view, include/balf_hip.h).
+        The reference exposes the same tensors to forward hooks on ``down1..down4``
+        (/root/reference/balf/model/mlp_ma_decoder.py:278-285); apply ``down4.conv2`` to the last one to get ``down4``'s."""
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        l = lib()
+        nbytes = l.balf_forward_workspace_bytes(b, h, w)
+        ws = ops._workspace("forward", dev, nbytes)
+        prec = self._code_of(self.effective_precision)
+        outs = []
+        with torch.cuda.device(dev):
+            for s in range(1, 5):
+                n = l.balf_forward_stage_view_numel(b, h, w, s)
+                if n == 0:
+                    raise ValueError(f"bad shape for stage_view: {(b, h, w)}")
+                sh = min(s, 3)
+                o = torch.empty((b, h >> sh, w >> sh, n // (b * (h >> sh) * (w >> sh))), dtype=torch.float32, device=dev)
+                check(l.balf_forward_stage_view(prec, ws.data_ptr(), ws.numel(), b, h, w, s, o.data_ptr(),
+                                                _lib.current_stream_ptr(dev)), "balf_forward_stage_view")
+                outs.append(o)
+        return outs
+
     def validate_fp16(self, x: torch.Tensor, tol: float = 1e-4) -> float:
         """Check the split-f16 path against the exact-fp32 path on ``x`` (a padded [B,3,H,W] batch): returns the
         max-abs score-map difference and raises if it exceeds ``tol`` or if the f16 path produced a non-finite value.

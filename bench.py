@@ -11,7 +11,8 @@ border 15, nms 15; weak scaling.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 --precision fp16 (default, and the module default) = f16 MFMA with split (hi+lo) operands, three products per
-MAC, fp32 accumulate/LayerNorm/GELU/softmax/NMS: score map within 1e-5 of the reference (north-star bar 1e-4).
+MAC, fp32 accumulate/LayerNorm/GELU/softmax/NMS: score map within 1e-4 of the CPU reference (the north-star bar;
+measured 4e-6 ... 6e-6 -- `index_match.prob_max_abs_err` in the line says what this run measured).
 --precision fp32 = exact fp32 MFMA.  The other precision is timed too and reported under "other_precision".
 
 Rank 0 prints ONE JSON line.  `value` = images/s over all GPUs; `keypoints_per_s` rides along.
@@ -19,10 +20,12 @@ Rank 0 prints ONE JSON line.  `value` = images/s over all GPUs; `keypoints_per_s
                 steps: balf_profile_begin/end in include/balf_hip.h) against the HBM roof (8 TB/s) and the dense f16 /
                 f32 MFMA peak of MI355X_MICROARCH.md; `traffic` = measured HBM bytes per launch and `issue` = the share
                 of the SIMDs' issue cycles its vector + matrix instructions need, both from the committed rocprofv3
-                --pmc passes of this script (profiles/r3_pmc.json); "bound" says which limit the kernel sits at.
+                --pmc passes of this script (profiles/rN_pmc.json, newest round); "bound" says which limit the kernel sits at.
   index_match   BASELINE's "NMS index match vs CPU ref": the images of the CPU sample against the oracle.
   cpu_baseline  the CPU oracle (a port of the reference path, oracle/) on a bounded sample, rank 0, N = 1.
-  other_configs the other BASELINE configurations that fit one GPU, a few steps each.
+  other_configs the other BASELINE configurations that fit one GPU, a few steps each, every entry with the roofline of ITS
+                dominant kernel (hipEvents of that run; PMC traffic only for the profiled shape) and a CPU baseline on two
+                of its images; `cpu_baseline.batched` is SURVEY 8(d)'s batch-min(B, 8) leg of the oracle at VGA.
 """
 from __future__ import annotations
 
@@ -51,7 +54,15 @@ def _import_product():
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, dense f32 MFMA
 PEAK_FP16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA (the hardware's peak: the split path spends 3 products per MAC)
 PEAK_HBM_GBS = 8000.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r3_pmc.json")
+def _newest_pmc_profile():
+    import glob
+    import re
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_pmc", os.path.basename(f)).group(1)))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r3_pmc.json")
+
+
+PMC_PROFILE = _newest_pmc_profile()
 C_STAGE = [32, 64, 128, 256]
 CIN_STAGE = [3, 32, 64, 128]
 
@@ -101,7 +112,7 @@ def kernel_flops_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
 
 
 def pmc_profile(precision: str, mb: int, hp: int, wp: int):
-    """The committed PMC passes (profiles/r3_pmc.json, tools/pmc_json.py): per profile slot, HBM bytes per launch and the
+    """The committed PMC passes (profiles/rN_pmc.json of the newest round, tools/pmc_json.py): per profile slot, HBM bytes per launch and the
     issue-slot accounting; None when they do not cover this shape."""
     if not (os.path.isfile(PMC_PROFILE) and mb == 8 and (hp, wp) == (1088, 1920)):
         return None
@@ -116,10 +127,12 @@ def synthetic_batch(h, w, lo, b):
     return np.stack([synth.synthetic_gray_u8(h, w, lo + i, blur=5 if i % 2 == 0 else 1) for i in range(b)])
 
 
-def cpu_baseline(gray, k, state, threads=0):
+def cpu_baseline(gray, k, state, threads=0, batch=1):
     """The CPU oracle (port of the reference path) on the images `gray` [n,H,W] uint8 of the same workload.  The path
     is layout/elementwise-bound on the CPU and slows down past a few dozen threads, so the thread count
     is capped (256 threads measured 34 s/image on the GPU box, 8 threads 6.6 s in the build container).
+    batch > 1: the forward runs on `batch` images per call (SURVEY 8d's batch-min(B, 8) leg; the reference itself only
+    ever calls the model with one image, /root/reference/balf/utils/train_utils.py:428).
     Returns (report, [padded score maps], [(idx raster order, score)])."""
     from oracle import oracle as O
     from oracle import c_oracle
@@ -131,19 +144,22 @@ def cpu_baseline(gray, k, state, threads=0):
     t_fwd = t_nms = 0.0
     probs, dets = [], []
     with torch.no_grad():
-        for i in range(n_images):
+        for i0 in range(0, n_images, batch):
             ta = time.perf_counter()
-            pad = O.mod_padding_symmetric(O.make_shape_even(imgs[i]), 64)
-            x = torch.tensor(pad, dtype=torch.float32).permute(2, 0, 1).unsqueeze(0)
-            prob = O.detector_forward(state, x)["prob"][0].numpy()
+            xs = []
+            for i in range(i0, min(i0 + batch, n_images)):
+                pad = O.mod_padding_symmetric(O.make_shape_even(imgs[i]), 64)
+                xs.append(torch.tensor(pad, dtype=torch.float32).permute(2, 0, 1))
+            pb = O.detector_forward(state, torch.stack(xs))["prob"].numpy()
             tb = time.perf_counter()
-            top, left = O.crop_offsets(h, w, *prob.shape)
-            idx, sc, _ = c_oracle.nms_topk(prob[top:top + h, left:left + w], 15, 15, k)
+            for prob in pb:
+                top, left = O.crop_offsets(h, w, *prob.shape)
+                idx, sc, _ = c_oracle.nms_topk(np.ascontiguousarray(prob[top:top + h, left:left + w]), 15, 15, k)
+                kp += idx.size
+                probs.append(prob)
+                dets.append((idx, sc))
             t_nms += time.perf_counter() - tb
             t_fwd += tb - ta
-            kp += idx.size
-            probs.append(prob)
-            dets.append((idx, sc))
     dt = time.perf_counter() - t0
     cpu_model = ""
     try:
@@ -155,7 +171,8 @@ def cpu_baseline(gray, k, state, threads=0):
            "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
            "keypoints_per_s": kp / dt,
            "forward_s_per_image": t_fwd / n_images, "nms_topk_s_per_image": t_nms / n_images,
-           "sample": f"{n_images} synthetic {w}x{h} gray images (the first of the GPU batch), batch 1, oracle forward "
+           "batch": batch,
+           "sample": f"{n_images} synthetic {w}x{h} gray images (the first of the GPU batch), batch {batch}, oracle forward "
                      f"(torch CPU fp32) + C NMS/top-{k}; {dt:.1f} s"}
     return rep, probs, dets
 
@@ -192,6 +209,21 @@ def _free_port():
     return p
 
 
+def rank_environment(env):
+    """What every rank of this bench needs in its environment, set in ONE place (launch_ranks for the ranks it starts,
+    main() for a rank some other launcher started, tests/test_rccl_gpu.py for its child): RCCL shares device buffers between
+    the ranks of a node through IPC handles, and the hosts of this pool only support the dmabuf kind -- without
+    HSA_ENABLE_IPC_MODE_LEGACY=0 a multi-rank group fails with `hipIpcGetMemHandle: invalid argument`.  A single-rank
+    group exchanges no handles and comes up either way (measured in round 3), which is why N = 1 never showed it."""
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    return env
+
+
+RANK_GRACE_S = float(os.environ.get("BALF_BENCH_GRACE_S", "20"))   # between terminate() and kill() of the ranks that survive a failed one
+LAUNCH_DEADLINE_S = float(os.environ.get("BALF_BENCH_DEADLINE_S", "1500"))     # the whole N-rank run
+
+
 def launch_ranks(n: int, argv) -> int:
     """`python bench.py --gpus N` without a launcher around it: start N fresh ranks of this script (one per GPU) and relay
     rank 0's JSON line.  This parent never touches the GPU (no torch.cuda call, no HIP call): a process that has
@@ -199,8 +231,7 @@ def launch_ranks(n: int, argv) -> int:
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set.
     Returns the exit status: 0 only if every rank exited 0 and rank 0 printed its line."""
     import subprocess
-    env0 = dict(os.environ)
-    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0 = rank_environment(dict(os.environ))
     env0.setdefault("MASTER_PORT", str(_free_port()))
     env0["WORLD_SIZE"] = env0["LOCAL_WORLD_SIZE"] = str(n)
     env0["BALF_BENCH_LAUNCHED"] = "1"
@@ -216,6 +247,8 @@ def launch_ranks(n: int, argv) -> int:
     reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
     reader.start()
     status, live = 0, dict(enumerate(procs))
+    t_start = time.monotonic()
+    t_term = None                                    # when the survivors were told to stop
     while live:
         for r, p in list(live.items()):
             rc = p.poll()
@@ -226,8 +259,27 @@ def launch_ranks(n: int, argv) -> int:
                 print(f"[bench] rank {r} exited with status {rc}", file=sys.stderr)
                 if status == 0:
                     status = rc if rc > 0 else 1
-                    for q in live.values():
-                        q.terminate()         # these exact children, nothing matched by pattern
+        now = time.monotonic()
+        if status == 0 and now - t_start > LAUNCH_DEADLINE_S:
+            print(f"[bench] the ranks did not finish within {LAUNCH_DEADLINE_S:.0f} s", file=sys.stderr)
+            status = 1
+        if status != 0 and live:
+            if t_term is None:
+                t_term = now
+                for q in live.values():
+                    q.terminate()             # these exact children, nothing matched by pattern
+            elif now - t_term > RANK_GRACE_S:
+                # a rank stuck in an RCCL or driver call may ignore SIGTERM: do not poll forever
+                for r, q in live.items():
+                    print(f"[bench] rank {r} ignored SIGTERM for {RANK_GRACE_S:.0f} s: killing it", file=sys.stderr)
+                    q.kill()
+                t_term = now + 3600.0         # (kill() cannot be ignored; wait() below reaps them)
+                for q in live.values():
+                    try:
+                        q.wait(timeout=10.0)
+                    except subprocess.TimeoutExpired:
+                        pass
+                live = {}
         time.sleep(0.05)
     reader.join(timeout=10.0)
     line0 = (buf[0] if buf else b"").decode()
@@ -248,8 +300,20 @@ def stub_main(args, json_fd):
     import torch.distributed as dist
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    if "MASTER_PORT" not in os.environ:
+        if world > 1:
+            raise SystemExit("[bench] MASTER_PORT is not set: the ranks of one run must agree on it")
+        os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("BALF_BENCH_TEST_FAULT") == "hang-after-failure":
+        # (tests/test_bench_launcher.py) rank 0 fails at once, the others ignore SIGTERM: the launcher must kill them
+        if rank == 0:
+            raise SystemExit(3)
+        import signal
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        time.sleep(3600)
+    if os.environ.get("BALF_BENCH_TEST_FAULT") == "hang-all":
+        time.sleep(3600)
     b, k = args.batch_per_gpu, args.topk
     g = torch.Generator().manual_seed(77 + rank)
     idx = torch.randint(0, 1 << 20, (b, k), generator=g, dtype=torch.int32)
@@ -278,7 +342,8 @@ def stub_main(args, json_fd):
                "per_rank_images_per_s": {"min": b * args.steps / dt_max, "max": b * args.steps / dt_min},
                "config": {"workload": f"stub: {b} x {k} fake keypoints per rank, all-gather only", "global_batch": b * world,
                           "parallelism": f"dp{world}"},
-               "launched_by": "bench.py" if os.environ.get("BALF_BENCH_LAUNCHED") else "external launcher"}
+               "launched_by": "bench.py" if os.environ.get("BALF_BENCH_LAUNCHED") else "external launcher",
+               "rank_env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}}
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()
@@ -380,6 +445,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # the driver's plain `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank_environment(os.environ)               # (before anything loads the HIP runtime)
     _import_product()
 
     # stdout carries exactly ONE line, the JSON: libraries that print banners there (RCCL prints its version block when
@@ -409,19 +475,25 @@ def main():
     collective_note = None
     have_group = False
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            raise SystemExit("[bench] MASTER_PORT is not set: the ranks of one run must agree on it")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         have_group = True
     elif not args.no_single_rank_collective:
         # one GPU: run the path's collective anyway on a single-rank RCCL group (SURVEY.md 8e caveat), so that the step
         # timed here is the step the N > 1 runs time
         try:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
             have_group = True
         except Exception as e:          # noqa: BLE001 -- report and go on without it
             collective_note = f"none (single-rank RCCL group failed: {type(e).__name__}: {e})"[:200]
+    # the library must be the release build: a timing-ablation build (csrc/diag.h) computes wrong results and only loads
+    # through an explicit BALF_HIP_LIB override, in which case the line says so instead of passing as a measurement
+    from balf_amd import _lib as _balf_lib
+    build_flags = _balf_lib.lib().balf_build_flags().decode()
+    if not build_flags.startswith("release"):
+        print(f"[bench] DIAGNOSTIC library build: {build_flags}", file=sys.stderr)
     h, w, k, b = args.height, args.width, args.topk, args.batch_per_gpu
     hp, wp, top, left = arch.padded_hw(h, w)
     state = synth.synthetic_state_dict(20240)
@@ -478,10 +550,10 @@ def main():
 
     rank_dt = [0.0, 0.0]                    # slowest / fastest rank's time of the last timed_run
 
-    mb = max(1, min(b, 16 * 1024 * 1024 // (hp * wp)))          # images per launch (make_plan in det_common.h)
-
-    def summarize(precision, dt_, prof_, steps):
-        """images/s + the roofline of the dominant kernel against both roofs and the issue limit."""
+    def summarize(precision, dt_, prof_, steps, b=b, hp=hp, wp=wp):
+        """images/s + the roofline of the dominant kernel against both roofs and the issue limit (b, hp, wp: the
+        configuration the profile was taken on; default: the headline one)."""
+        mb = max(1, min(b, 16 * 1024 * 1024 // (hp * wp)))          # images per launch (make_plan in det_common.h)
         name, (ms, n_launch) = max(prof_.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / n_launch
         flops = kernel_flops_per_launch(name, mb, hp, wp)
@@ -529,16 +601,16 @@ def main():
                 "achieved_GBps": tot * (b / mb) / (fwd_ms * 1e-3) / 1e9,
                 "frac_of_8TBps": tot * (b / mb) / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 "reference_points_bytes_per_px": {"algorithmic_minimum": 20.0, "fused_schedule_plan_fp16": 1100.0},
-                "source": "profiles/r3_pmc.json"}
+                "source": os.path.relpath(PMC_PROFILE, ROOT)}
         return out_
 
     step = make_step(x, h, w, k)
     dt, prof, out = timed_run(step, args.steps, args.warmup)
-    if model.precision != args.precision:
-        # the module switches itself to the fp32 kernels when a checkpoint fails its split-f16 range check (a warning for a
-        # caller, but a number measured on the other path under this path's name for a benchmark)
-        raise SystemExit(f"[bench] the model left precision={args.precision!r} for {model.precision!r} (split-f16 range check "
-                         "failed): refusing to report")
+    if model.effective_precision != args.precision:
+        # the module runs a checkpoint that fails its split-f16 range check on the fp32 kernels (a warning for a caller,
+        # but a number measured on the other path under this path's name for a benchmark)
+        raise SystemExit(f"[bench] the model ran precision={model.effective_precision!r} instead of {args.precision!r} "
+                         "(split-f16 range check failed): refusing to report")
     counts = out[2]
     kp_per_image = float(counts.float().mean().item())
     head = summarize(args.precision, dt, prof, args.steps)
@@ -559,6 +631,20 @@ def main():
         e1.record()
         fence()
         allgather_us = e0.elapsed_time(e1) * 1e3 / 20
+    # every rank must end up with the SAME gathered slabs, its own shard at rows [rank * b, (rank + 1) * b)
+    slabs_identical = None
+    if have_group:
+        gi_, gs_, gc_ = out[0], out[1], out[2]
+        own = (torch.equal(gi_[rank * b:(rank + 1) * b], out[3][0]) and torch.equal(gc_[rank * b:(rank + 1) * b], out[3][2])
+               and gi_.shape[0] == world * b)
+        w8 = torch.arange(1, gi_.numel() + 1, device=dev, dtype=torch.int64).view(gi_.shape) % 1000003      # order-sensitive
+        chk = torch.stack([(gi_.long() * w8).sum(), (gs_.view(torch.int32).long() * w8).sum(), gc_.long().sum(),
+                           torch.tensor(int(own), device=dev)])
+        allc = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        slabs_identical = bool(all(torch.equal(c_[:3], allc[0][:3]) for c_ in allc) and all(int(c_[3]) == 1 for c_ in allc))
+        if not slabs_identical:
+            raise SystemExit(f"[bench] rank {rank}: the gathered keypoint slabs differ between ranks (or a shard is misplaced)")
     gpu_sample = tuple(t[:max(args.cpu_images, 1)].clone() for t in out[3])     # this rank's first images
 
     other = None
@@ -570,22 +656,39 @@ def main():
         other["precision"] = other_prec
         model.precision = args.precision
 
-    # the other BASELINE configurations that fit one GPU (driver-timed too: a few steps each)
+    # the other BASELINE configurations that fit one GPU (driver-timed too: a few steps each), each with the roofline of its
+    # own dominant kernel and -- rank 0 -- a CPU baseline on two of its images (north_star: "throughput on synthetic
+    # VGA/720p/1080p ... as absolute numbers and as fraction of the HBM/MFMA roofline, next to the reference CPU path")
     other_cfgs = None
     if world == 1 and args.other_configs and (h, w, b) == (1080, 1920, 32):
         other_cfgs = []
         del x
+        cpu_done = {}
         for (name, bb, hh, ww, kk, prec, steps) in (("configs[1]: 32 x 640x480, top-1000", 32, 480, 640, 1000, "fp16", 5),
                                                     ("configs[2]: 64 x 1280x720, top-2000, fp32", 64, 720, 1280, 2000, "fp32", 2),
                                                     ("configs[2] on the split-f16 path", 64, 720, 1280, 2000, "fp16", 3),
                                                     ("configs[4]: 128 x 1920x1080 fp16, top-2000 (1 GPU)", 128, 1080, 1920, 2000, "fp16", 2)):
             model.precision = prec
-            xx = resident_input(synthetic_batch(hh, ww, 0, min(bb, 8)).repeat((bb + 7) // 8, axis=0)[:bb], hh, ww)
+            g8 = synthetic_batch(hh, ww, 0, min(bb, 8))
+            xx = resident_input(g8.repeat((bb + 7) // 8, axis=0)[:bb], hh, ww)
             st = make_step(xx, hh, ww, kk)
-            d, _, o = timed_run(st, steps, 1)
-            other_cfgs.append({"workload": name, "precision": prec, "images_per_s": bb * steps / d,
-                               "keypoints_per_s": bb * steps / d * float(o[2].float().mean().item()),
-                               "ms_per_step": d / steps * 1e3, "steps": steps})
+            d, pf, o = timed_run(st, steps, 1)
+            hp_, wp_, top_, left_ = arch.padded_hw(hh, ww)
+            sm = summarize(prec, d, pf, steps, b=bb, hp=hp_, wp=wp_)
+            entry = {"workload": name, "precision": prec, "images_per_s": bb * steps / d,
+                     "keypoints_per_s": bb * steps / d * float(o[2].float().mean().item()),
+                     "ms_per_step": d / steps * 1e3, "steps": steps, "roofline": sm["roofline"],
+                     "forward_tflops": sm["forward_tflops"], "kernels_ms_per_step": sm["kernels_ms_per_step"]}
+            if args.cpu_images > 0 and (hh, ww) != (h, w):
+                # the CPU oracle on the first two images of this configuration (once per size; 1080p has the headline's)
+                if (hh, ww) not in cpu_done:
+                    rep, cprobs, cdets = cpu_baseline(g8[:2], kk, state, args.cpu_threads)
+                    cpu_done[(hh, ww)] = (rep, cprobs, cdets)
+                rep, cprobs, cdets = cpu_done[(hh, ww)]
+                entry["cpu_baseline"] = rep
+                gpu_s = tuple(t[:2].clone() for t in o[3])
+                entry["index_match"] = dict(index_match(gpu_s, cprobs, cdets, hh, ww, kk, top_, left_), precision=prec)
+            other_cfgs.append(entry)
             del xx, st, o
         model.precision = args.precision
         torch.cuda.empty_cache()
@@ -607,11 +710,14 @@ def main():
             collective_note = ("all_gather_into_tensor of [B,2K+1] int32 keypoint slabs (RCCL)"
                                + ("" if world > 1 else ", single-rank group") if have_group else "none")
         res = {
-            "metric": "images/sec + keypoints/sec on 1080p gray (detector forward + NMS + top-K); NMS index match vs CPU ref",
+            "metric": ("images/sec + keypoints/sec on 1080p gray (detector forward + NMS + top-K); NMS index match vs CPU ref"
+                       if build_flags.startswith("release") else "INVALID: diagnostic library build (timing ablation, wrong results)"),
             "value": ips, "unit": "images/s", "keypoints_per_s": ips * kp_per_image,
             "keypoints_per_image": kp_per_image,
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if have_group else 0,
             "per_rank_images_per_s": per_rank, "allgather_device_us": allgather_us,
+            "gathered_slabs_identical": slabs_identical,
+            "rank_env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
             "launched_by": "bench.py" if os.environ.get("BALF_BENCH_LAUNCHED") else
                            ("external launcher" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "direct"),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
@@ -633,12 +739,17 @@ def main():
             "other_configs": other_cfgs,
             "batch1_latency": latency,
             "power_state_under_load": power,
+            "library_build": build_flags,
         }
         if world == 1 and args.cpu_images > 0:
             n = min(args.cpu_images, b)
             res["cpu_baseline"], cpu_probs, cpu_dets = cpu_baseline(gray[:n], k, state, args.cpu_threads)
             res["index_match"] = index_match(gpu_sample, cpu_probs, cpu_dets, h, w, k, top, left)
             res["index_match"]["precision"] = args.precision
+            if other_cfgs is not None:
+                # SURVEY 8(d)'s second CPU leg: the oracle with batch = min(B, 8) images per forward call, at VGA
+                res["cpu_baseline"]["batched"] = cpu_baseline(synthetic_batch(480, 640, 0, 8), 1000, state, args.cpu_threads,
+                                                              batch=8)[0]
         else:
             res["cpu_baseline"] = None
             res["index_match"] = None

@@ -47,7 +47,12 @@ extern "C" {
 
 /* precision of the Linear-layer contractions (everything else is always fp32) */
 #define BALF_PREC_FP32 0         /* v_mfma_f32_16x16x4_f32, exact fp32 fma chains                  */
-#define BALF_PREC_FP16 1         /* v_mfma_f32_16x16x32_f16, fp16 operands, fp32 accumulate        */
+#define BALF_PREC_FP16 1         /* f16 MFMA with SPLIT operands: every operand is carried as hi = f16(v) and
+                                    lo = f16(v - hi), a product is hi*hi' + lo*hi' + hi*lo' accumulated in fp32
+                                    (v_mfma_f32_32x32x16_f16 in the persistent kernels of the early stages,
+                                    v_mfma_f32_16x16x32_f16 elsewhere; conv0 of stage 1 as exact f32 MFMA): score
+                                    map within ~6e-6 of the fp32 reference.  Operands must stay inside the f16
+                                    range (|v| < 6.5e4): see MLP_MA_DECODER.validate_fp16 on the Python side     */
 
 int balf_abi_version(void);
 const char *balf_error_string(int code);
@@ -90,6 +95,19 @@ int balf_forward(const void *packed_dev, int precision, const float *x_nchw_dev,
 int balf_forward_u8(const void *packed_dev, int precision, const unsigned char *image_dev, int channels, int B,
                     int H, int W, float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
                     void *stream);
+
+/* Validation aid (not part of the data path): the activation that crosses stage boundary `stage` of the forward that last
+ * ran on `workspace_dev` with the same (precision, B, Hp, Wp), as plain fp32 NHWC in out_dev:
+ *   stage 1..3  Down.forward's return value of down1..down3 (mlp_ma_decoder.py:223-244: after MaxPool2d), i.e. the next
+ *               stage's input: [B, Hp/2^s, Wp/2^s, C_s], C = 32/64/128 (the split-f16 path keeps these as hi+lo f16
+ *               fragments in the workspace; the view adds the halves);
+ *   stage 4     x2 = t * s + x1 + x0 of down4 BEFORE its conv2 (:239-241; conv2 runs inside the head kernel and its output
+ *               never exists in memory): [B, Hp/8, Wp/8, 256] -- apply down4.conv2 to compare with the reference's down4.
+ * Only the last micro-batch of a forward is resident in the workspace: B must not exceed it (BALF_ERR_ARG otherwise; 8
+ * images at 1088x1920, more at smaller sizes).  balf_forward_stage_view_numel = elements of out_dev (0: bad arguments). */
+size_t balf_forward_stage_view_numel(int B, int Hp, int Wp, int stage);
+int balf_forward_stage_view(int precision, const void *workspace_dev, size_t workspace_bytes, int B, int Hp, int Wp, int stage,
+                            float *out_dev, void *stream);
 
 /* ---- window-max NMS, dense form (apply_nms) ------------------------------------------------
  * score_dev [B,H,W] fp32 -> out_dev [B,H,W] fp32 = rb * (rb == max over the clipped

@@ -544,10 +544,14 @@ def warp_perspective_linear(src: np.ndarray, m: np.ndarray, dsize) -> np.ndarray
             at(sy + 1, sx) * ((1 - ax) * ay) + at(sy + 1, sx + 1) * (ax * ay))
 
 
-def create_common_region_masks(h_dst_2_src, shape_src, shape_dst):
-    """geometry_tools.py:7-26 with ``warp_perspective_linear`` in the place of cv2.warpPerspective."""
+def create_common_region_masks(h_dst_2_src, shape_src, shape_dst, numpy_inverse: bool = True):
+    """geometry_tools.py:7-26 with ``warp_perspective_linear`` in the place of cv2.warpPerspective.
+    numpy_inverse=True (default) is the reference's own statement, ``inv_h = np.linalg.inv(h_dst_2_src)`` (:9, LAPACK's LU);
+    False takes the closed-form ``invert3`` there too -- operation for operation what balf_common_region_masks computes, so
+    that kernel and oracle can be compared for EQUALITY.  The two inverses differ in the last bits, which can move a source
+    coordinate across a 1/32-pixel rounding tie: a handful of mask pixels at most (tests/test_repeat_gpu.py checks both)."""
     h_dst_2_src = np.asarray(h_dst_2_src, dtype=np.float64)
-    inv_h = invert3(h_dst_2_src)                     # (the reference: np.linalg.inv; equal up to the last bits)
+    inv_h = np.linalg.inv(h_dst_2_src) if numpy_inverse else invert3(h_dst_2_src)
     inv_h = inv_h / inv_h[2, 2]
     ones_dst = remove_borders(np.ones((shape_dst[0], shape_dst[1])), 15)
     mask_src = warp_perspective_linear(ones_dst, h_dst_2_src, (shape_src[1], shape_src[0]))

@@ -94,3 +94,42 @@ def test_launcher_parent_does_not_load_torch_or_the_library():
             "print('clean')\n") % (STUB, BENCH)
     r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "clean", r.stderr[-2000:]
+
+
+def test_ranks_get_the_rccl_environment_from_one_place():
+    """the multi-rank RCCL group needs dmabuf IPC on this pool (HSA_ENABLE_IPC_MODE_LEGACY=0); the launcher,
+    a rank under another launcher and the GPU test's child all take it from bench.rank_environment."""
+    env = _env()
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + STUB, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _one_line(r.stdout)["rank_env"] == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2"] + STUB,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _one_line(r.stdout)["rank_env"] == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    # an explicit setting of the caller's wins
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + STUB, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and _one_line(r.stdout)["rank_env"] == {"HSA_ENABLE_IPC_MODE_LEGACY": "1"}
+
+
+def test_a_rank_that_ignores_sigterm_is_killed():
+    """after a rank fails the launcher terminates the others, and a rank that does not die on SIGTERM (stuck in
+    a collective or a driver call) is killed after a bounded grace period instead of being polled forever."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3"] + STUB,
+                       env=_env(BALF_BENCH_TEST_FAULT="hang-after-failure", BALF_BENCH_GRACE_S="2"), capture_output=True,
+                       text=True, timeout=120)
+    took = time.monotonic() - t0
+    assert r.returncode == 3 and r.stdout.strip() == "", (r.returncode, r.stdout, r.stderr[-1500:])
+    assert "ignored SIGTERM" in r.stderr and took < 60, (took, r.stderr[-1500:])
+
+
+def test_the_whole_run_has_a_deadline():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + STUB,
+                       env=_env(BALF_BENCH_TEST_FAULT="hang-all", BALF_BENCH_DEADLINE_S="3", BALF_BENCH_GRACE_S="1"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "did not finish within" in r.stderr, r.stderr[-1500:]

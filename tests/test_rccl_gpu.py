@@ -45,9 +45,42 @@ def _free_port():
     return p
 
 
+def _rank_env(**kw):
+    """the RCCL environment of a rank comes from ONE place, bench.rank_environment (imports nothing GPU-related)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.rank_environment(dict(os.environ, **kw))
+
+
 def test_allgather_keypoints_single_rank_rccl():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
-               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = _rank_env(MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0") and env["MASTER_ADDR"]
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT)], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "RCCL_SINGLE_RANK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()           # (counting devices does not initialise the GPU)
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs (the build's gpurun boxes have one; an 8-GPU node runs it)")
+def test_allgather_two_ranks():
+    """The first REAL N > 1 step: `python bench.py --gpus 2` -- the driver's command form -- starts two
+    fresh ranks from a parent that never touches the GPU; each runs forward + NMS + top-K on its shard and the RCCL
+    all-gather over xGMI; bench.py itself verifies on every rank that the gathered slabs are identical and that the rank's own
+    shard sits at its rows, and refuses to print a line otherwise."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--other-configs", "0", "--other-steps", "0", "--cpu-images", "0"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["launched_by"] == "bench.py"
+    assert res["gathered_slabs_identical"] is True and res["config"]["global_batch"] == 64
+    assert res["rank_env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert res["value"] > 0 and res["per_rank_images_per_s"]["min"] > 0
