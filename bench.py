@@ -670,7 +670,7 @@ def main():
                                                     ("configs[4]: 128 x 1920x1080 fp16, top-2000 (1 GPU)", 128, 1080, 1920, 2000, "fp16", 2)):
             model.precision = prec
             g8 = synthetic_batch(hh, ww, 0, min(bb, 8))
-            xx = resident_input(g8.repeat((bb + 7) // 8, axis=0)[:bb], hh, ww)
+            xx = resident_input(np.tile(g8, ((bb + 7) // 8, 1, 1))[:bb], hh, ww)       # images 0..7, 0..7, ...
             st = make_step(xx, hh, ww, kk)
             d, pf, o = timed_run(st, steps, 1)
             hp_, wp_, top_, left_ = arch.padded_hw(hh, ww)
