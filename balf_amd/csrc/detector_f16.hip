@@ -21,6 +21,8 @@
 // Activations that are consumed as B operands straight from HBM (stage inputs X2..X4 and the grid-branch
 // output U) are stored pre-split in "fragment format": per pixel, per K-step 128 B = [hi: q0..q3 x 8
 // halves][lo: q0..q3 x 8 halves] -- the same bytes per pixel as fp32 NHWC.
+#include <stdlib.h>
+
 #include <mutex>
 #include <type_traits>
 
@@ -364,20 +366,21 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
 }
 
 #include "stage1_f16.h"
+#include "stage2_f16.h"
 #include "stage_cs_f16.h"
 
 // Stages 1-3 leave x1 + the hidden-layer channel sums and a tail kernel forms the next stage's input; stage 4 stores t and
 // r for the head kernel.
-template <int C> constexpr bool stage_fused() { return C == 32 || cs_fused<C>(); }
+template <int C> constexpr bool stage_fused() { return C == 32 || C == 64 || cs_fused<C>(); }
 
 // ---- dynamic-LDS sizes of every kernel this file launches, and their one-time registration ----
 template <int C, int MODE> constexpr int cs_launch_lds() {
     return MODE == 2 ? cs_tail_lds_bytes<C>() * cs_groups<C>() : cs_lds_bytes<C>() * cs_groups<C>() + cs_lut_bytes<MODE>();
 }
 static_assert(s1_lds_bytes<0>() <= 160 * 1024 && s1_lds_bytes<1>() <= 160 * 1024 && s1_lds_bytes<2>() <= 160 * 1024, "stage-1 LDS image");
-static_assert(cs_launch_lds<64, 0>() <= 160 * 1024 && cs_launch_lds<64, 1>() <= 160 * 1024 && cs_launch_lds<128, 0>() <= 160 * 1024 &&
-              cs_launch_lds<128, 1>() <= 160 * 1024 && cs_launch_lds<256, 0>() <= 160 * 1024 && cs_launch_lds<256, 1>() <= 160 * 1024,
-              "channel-split LDS image");
+static_assert(s2_lds_bytes<0>() <= 160 * 1024 && s2_lds_bytes<1>() <= 160 * 1024 && s2_lds_bytes<2>() <= 160 * 1024, "stage-2 LDS image");
+static_assert(cs_launch_lds<128, 0>() <= 160 * 1024 && cs_launch_lds<128, 1>() <= 160 * 1024 && cs_launch_lds<256, 0>() <= 160 * 1024 &&
+              cs_launch_lds<256, 1>() <= 160 * 1024, "channel-split LDS image");
 
 template <typename K>
 bool allow_lds(K k, int bytes) {
@@ -397,8 +400,8 @@ int ensure_kernel_attributes() {
     ok = ok && allow_lds(stage1_kernel16<0, false>, s1_lds_bytes<0>()) && allow_lds(stage1_kernel16<0, true>, s1_lds_bytes<0>());
     ok = ok && allow_lds(stage1_kernel16<1, false>, s1_lds_bytes<1>()) && allow_lds(stage1_kernel16<1, true>, s1_lds_bytes<1>());
     ok = ok && allow_lds(stage1_kernel16<2, false>, s1_lds_bytes<2>()) && allow_lds(stage1_kernel16<2, true>, s1_lds_bytes<2>());
-    ok = ok && allow_lds(stage_cs_kernel16<64, 32, 0>, cs_launch_lds<64, 0>()) && allow_lds(stage_cs_kernel16<64, 32, 1>, cs_launch_lds<64, 1>()) &&
-         allow_lds(stage_cs_kernel16<64, 32, 2>, cs_launch_lds<64, 2>());
+    ok = ok && allow_lds(stage2_kernel16<0>, s2_lds_bytes<0>()) && allow_lds(stage2_kernel16<1>, s2_lds_bytes<1>()) &&
+         allow_lds(stage2_kernel16<2>, s2_lds_bytes<2>());
     ok = ok && allow_lds(stage_cs_kernel16<128, 64, 0>, cs_launch_lds<128, 0>()) && allow_lds(stage_cs_kernel16<128, 64, 1>, cs_launch_lds<128, 1>()) &&
          allow_lds(stage_cs_kernel16<128, 64, 2>, cs_launch_lds<128, 2>());
     ok = ok && allow_lds(stage_cs_kernel16<256, 128, 0>, cs_launch_lds<256, 0>()) && allow_lds(stage_cs_kernel16<256, 128, 1>, cs_launch_lds<256, 1>());
@@ -419,9 +422,14 @@ template <int C, int CIN>
 int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
                 float *partial, float *chunk, float *scale, hipStream_t st) {
     StageArgs a{blob, kLayout.st[s], X, u8.p, u8.ch, u8.h, u8.w, u8.top, u8.left, B, H, W, U, T, R, partial};
-    const int per_img = (H / 8) * (W / 8);                 // one partial-sum row per token group
-    const long groups = (long)B * per_img;
-    if constexpr (C == 32) {
+    const int rows_per_group = (C == 64) ? 2 : 1;           // partial-sum rows per token group (stage 2: one per wave half)
+    const int per_img = (H / 8) * (W / 8) * rows_per_group;
+    const long groups = (long)B * (H / 8) * (W / 8);
+    if constexpr (C == 64) {
+        // persistent token-split kernels (stage2_f16.h): one workgroup per CU at most, every wave PAIR walks its own list of groups
+        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(stage2_kernel16<0>, dim3(s1_blocks(groups, s2_waves<0>() / 2)), dim3(s2_waves<0>() * 64), s2_lds_bytes<0>(), st, a));
+        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(stage2_kernel16<1>, dim3(s1_blocks(groups, s2_waves<1>() / 2)), dim3(s2_waves<1>() * 64), s2_lds_bytes<1>(), st, a));
+    } else if constexpr (C == 32) {
         auto g0 = u8.ch ? stage1_kernel16<0, true> : stage1_kernel16<0, false>;
         auto g1 = u8.ch ? stage1_kernel16<1, true> : stage1_kernel16<1, false>;
         BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(g0, dim3(s1_blocks(groups, s1_waves<0>())), dim3(s1_waves<0>() * 64), s1_lds_bytes<0>(), st, a));
@@ -451,14 +459,20 @@ template <int C, int CIN>
 int run_tail_cs16(const float *blob, int s, const float *X, const float *R, const float *scale, int B, int H, int W, float *out,
                   hipStream_t st) {
     StageArgs a{blob, kLayout.st[s], X, nullptr, 0, 0, 0, 0, 0, B, H, W, nullptr, nullptr, const_cast<float *>(R), nullptr, scale, out};
-    constexpr int G = cs_groups<C>();
     const long groups = (long)B * (H / 8) * (W / 8);
-    if (groups % G != 0) return BALF_ERR_ARG;
-    auto k = stage_cs_kernel16<C, CIN, 2>;
-    constexpr int lds = cs_launch_lds<C, 2>();
-    BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(k, dim3((unsigned)(groups / G)), dim3(cs_waves<C>() * G * 64), lds, st, a));
-    BALF_LAUNCH_CHECK();
-    return BALF_OK;
+    if constexpr (C == 64) {
+        BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(stage2_kernel16<2>, dim3(s1_blocks(groups, s2_waves<2>() / 2)), dim3(s2_waves<2>() * 64), s2_lds_bytes<2>(), st, a));
+        BALF_LAUNCH_CHECK();
+        return BALF_OK;
+    } else {
+        constexpr int G = cs_groups<C>();
+        if (groups % G != 0) return BALF_ERR_ARG;
+        auto k = stage_cs_kernel16<C, CIN, 2>;
+        constexpr int lds = cs_launch_lds<C, 2>();
+        BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(k, dim3((unsigned)(groups / G)), dim3(cs_waves<C>() * G * 64), lds, st, a));
+        BALF_LAUNCH_CHECK();
+        return BALF_OK;
+    }
 }
 
 // Stage-1 tail (stage1_kernel16<2>): x1 (in R), the image and the SE scale -> the next stage's input.
@@ -510,6 +524,9 @@ int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
         if ((rc = run_tail16(blob, x, u8b, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
         if ((rc = run_stage16<64, 32>(blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_tail_cs16<64, 32>(blob, 1, X2, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
+#if BALF_DEBUG_STOP
+        if (const char *e = getenv("BALF_DEBUG_STOP_STAGE"); e && atoi(e) == 2) return BALF_OK;
+#endif
         if ((rc = run_stage16<128, 64>(blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_tail_cs16<128, 64>(blob, 2, X3, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
         if ((rc = run_stage16<256, 128>(blob, 3, X4, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;

@@ -35,13 +35,16 @@
 #ifndef BALF_HN_STAMPS
 #define BALF_HN_STAMPS 0         // the same in the HardNet kernels (hardnet.hip)
 #endif
+#ifndef BALF_DEBUG_STOP
+#define BALF_DEBUG_STOP 0        // the f16 forward stops after the stage named by the environment variable BALF_DEBUG_STOP_STAGE (tools/s2_debug.py)
+#endif
 #ifndef BALF_S1_STRICT
 #define BALF_S1_STRICT 0         // every hand-placed vmcnt wait of the persistent kernels drains the queue (debugging aid: correct, slow)
 #endif
 
 #define BALF_DIAGNOSTIC_BUILD                                                                                      \
     (BALF_ABLATE_GELU || BALF_ABLATE_BARRIER || BALF_ABLATE_LOADLAT || BALF_ABLATE_LUTCOPY || BALF_ABLATE_WSTREAM || \
-     BALF_ABLATE_SPLIT || BALF_DROP_WLO || BALF_STAMPS || BALF_HN_STAMPS || BALF_S1_STRICT)
+     BALF_ABLATE_SPLIT || BALF_DROP_WLO || BALF_STAMPS || BALF_HN_STAMPS || BALF_S1_STRICT || BALF_DEBUG_STOP)
 #if BALF_DIAGNOSTIC_BUILD && !defined(BALF_ALLOW_DIAGNOSTIC_BUILD)
 #error "a diagnostic switch (csrc/diag.h) is set: pass -DBALF_ALLOW_DIAGNOSTIC_BUILD=1 as well (tools/build_variant.sh does) -- such a library must not ship"
 #endif
@@ -52,4 +55,5 @@
 #define BALF_DIAG_FLAGS_STRING                                                                                     \
     BALF_DIAG_ITEM(BALF_ABLATE_GELU) BALF_DIAG_ITEM(BALF_ABLATE_BARRIER) BALF_DIAG_ITEM(BALF_ABLATE_LOADLAT)        \
     BALF_DIAG_ITEM(BALF_ABLATE_LUTCOPY) BALF_DIAG_ITEM(BALF_ABLATE_WSTREAM) BALF_DIAG_ITEM(BALF_ABLATE_SPLIT)       \
-    BALF_DIAG_ITEM(BALF_DROP_WLO) BALF_DIAG_ITEM(BALF_STAMPS) BALF_DIAG_ITEM(BALF_HN_STAMPS) BALF_DIAG_ITEM(BALF_S1_STRICT)
+    BALF_DIAG_ITEM(BALF_DROP_WLO) BALF_DIAG_ITEM(BALF_STAMPS) BALF_DIAG_ITEM(BALF_HN_STAMPS) BALF_DIAG_ITEM(BALF_S1_STRICT) \
+    BALF_DIAG_ITEM(BALF_DEBUG_STOP)

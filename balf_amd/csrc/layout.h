@@ -23,6 +23,9 @@ constexpr float kBnEps = 1e-5f;
 // (a, b) pair per interval with gelu(x) ~ a + b x, plus the two exact asymptotes (entry 0: 0, entry N: x)
 constexpr int kGeluLutN = 3072;
 constexpr float kGeluLutL = 6.0f;
+// the same table with 2048 intervals (16 KB instead of 24): the stage-2 block kernel (stage2_f16.h), whose LDS also holds
+// 104 KB of weights and the token tiles; chord error 1.7e-6 instead of 7.6e-7
+constexpr int kGeluLut2N = 2048;
 // GELU table of the channel-split kernels (stage_cs_f16.h), which have 6 KB of LDS to spare, not 24: gelu(x) = x / 2 +
 // E(|x|), E(a) = a erf(a / sqrt 2) / 2, chords of E over intervals whose width doubles where the curvature allows it:
 // kGeluLogM intervals each over |x| in [0, 1), [1, 3), [3, 7) -- the binades of (|x| + 1) / 8, so the interval index is
@@ -33,7 +36,7 @@ constexpr int kGeluLogEntries = 3 * kGeluLogM + 1;
 // Which stages' split-f16 weights are packed as fragments of v_mfma_f32_32x32x16_f16 (weights.hip: pack_frags32) instead
 // of v_mfma_f32_16x16x32_f16 (pack_frags16); the fp32 blob is not affected.  Stage s's OUTPUT activation (the next stage's
 // input X, fragment format in HBM) follows the format of the stage that CONSUMES it.
-constexpr bool kFmt32[kStages] = {true, false, false, false};
+constexpr bool kFmt32[kStages] = {true, true, false, false};
 constexpr bool kFmt32Head = false;
 
 struct BranchOff {                // GridGmlpLayer / BlockGmlpLayer
@@ -66,6 +69,7 @@ struct Layout {
     int u8_lut;                   // [256] float32(i / 255.0): uint8 image -> network input (demo_match.py:22)
     int gelu_lut;                 // [kGeluLutN + 1][2] chord table of the exact GELU (see kGeluLutN)
     int gelu_log;                 // [kGeluLogEntries][2] chord table of E(|x|) (see kGeluLogM)
+    int gelu_lut2;                // [kGeluLut2N + 1][2] chord table of the exact GELU, coarser (see kGeluLut2N)
     int total;                    // floats
 };
 
@@ -105,6 +109,7 @@ constexpr Layout make_layout() {
     L.u8_lut = take(256);
     L.gelu_lut = take(2 * (kGeluLutN + 1));
     L.gelu_log = take(2 * kGeluLogEntries);
+    L.gelu_lut2 = take(2 * (kGeluLut2N + 1));
     L.total = o;
     return L;
 }

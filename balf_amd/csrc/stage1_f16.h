@@ -203,13 +203,14 @@ __device__ __forceinline__ void lrelu32(f16v (&t)[N]) {
 //   gelu = a + b x
 // 3 vector instructions (9.4 issue cycles at the measured class rates) + 1 LDS read against 8 (33 cycles) for the 2^P
 // form; the LDS pipe of these kernels was idle three quarters of the time.  Chord error 7.6e-7 (the 2^P form: 6.4e-7).
+template <int LUTN = kGeluLutN>
 __device__ __forceinline__ unsigned gelu_lut_off(float x, float magic) {
-    static_assert((kGeluLutN + 1) * 8 <= 0x8000, "the byte offset mask below is 15 bits");
+    static_assert((LUTN + 1) * 8 <= 0x8000, "the byte offset mask below is 15 bits");
     // (x is an MFMA result: the instruction that reads it must be the compiler's -- hipcc pads the MFMA -> VALU read
     // hazard for its own instructions only, an inline-asm v_fma placed right behind the MFMA read stale registers;
     // fmed3(., 0, 1) folds into the fma's clamp modifier)
     const float y = __builtin_amdgcn_fmed3f(fmaf(x, 0.5f / kGeluLutL, 0.5f), 0.0f, 1.0f);
-    const float t = fmaf(y, 8.0f * kGeluLutN, magic);
+    const float t = fmaf(y, 8.0f * LUTN, magic);
     return __builtin_bit_cast(unsigned, t) & 0x7FF8u;
 }
 
@@ -225,7 +226,7 @@ __device__ __forceinline__ unsigned gelu_lut_off(float x, float magic) {
 #ifndef BALF_S1_GELU_CH
 #define BALF_S1_GELU_CH 8
 #endif
-template <int CH>
+template <int CH, int LUTN = kGeluLutN>
 __device__ __forceinline__ void gelu_lut_pipe(f16v (&t)[2], float magic) {
     constexpr int NCH = 32 / CH;
     typedef const f2 __attribute__((address_space(3))) *lds_f2_ptr;
@@ -236,7 +237,7 @@ __device__ __forceinline__ void gelu_lut_pipe(f16v (&t)[2], float magic) {
     f2 ab[2][CH];
     auto issue = [&](int c, int buf) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) ab[buf][i] = *reinterpret_cast<lds_f2_ptr>(gelu_lut_off(v[c * CH + i], magic));
+        for (int i = 0; i < CH; ++i) ab[buf][i] = *reinterpret_cast<lds_f2_ptr>(gelu_lut_off<LUTN>(v[c * CH + i], magic));
     };
     auto finish = [&](int c, int buf) {
 #pragma unroll

@@ -112,8 +112,8 @@ void pack_frags16(float *dst_region, const float *W, int N, int K, int Npad, boo
 //              registers 8 s .. 8 s + 7 of lane half h (channels 8 g + 4 h + r, g = 2 s, 2 s + 1) are K-step s' K-slots;
 //   natural:   W[row(R, m)][16 s + 8 h + j]                     -- the token-mix matrix (K = token index read linearly
 //              from the transposed tile in LDS).
-// row(R, m) = 32 R + m, or for the token-mix matrix (`token_rows`) 2 m + R: output tile R holds the tokens the lane
-// columns of pixel tile R carry (token t = 2 n + p, stage1_f16.h).
+// row(R, m) = 32 R + m, or for the token-mix matrix of stage 1 (`token_rows`) 2 m + R: output tile R holds the tokens the
+// lane columns of pixel tile R carry (token t = 2 n + p, stage1_f16.h; stage 2: token t = 32 R + n, stage2_f16.h).
 void pack_frags32(float *dst_region, const float *W, int N, int K, int Npad, bool permuted, bool token_rows) {
     _Float16 *dst = reinterpret_cast<_Float16 *>(dst_region);
     const int KS = K / 16;
@@ -212,7 +212,7 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
             copy(blob + B.d1_b, bf.data(), 2 * C);
             copy(blob + B.gln_g, u[4], C);
             copy(blob + B.gln_b, u[5], C);
-            if (f16 && fmt32) pack_frags32(blob + B.mix_w, u[6], kTokens, kTokens, kTokens, false, true);
+            if (f16 && fmt32) pack_frags32(blob + B.mix_w, u[6], kTokens, kTokens, kTokens, false, /*token_rows=*/s == 0);
             else if (f16) pack_frags16(blob + B.mix_w, u[6], kTokens, kTokens, kTokens, false);
             else pack_frags(blob + B.mix_w, u[6], kTokens, kTokens, kTokens);
             copy(blob + B.mix_b, u[7], kTokens);
@@ -254,19 +254,23 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
     // (x >= L - h/16) exactly x: |gelu - asymptote| < 7e-9 out there.
     {
         auto g = [](double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752440)); };
-        const double L = (double)kGeluLutL, hh = 2.0 * L / kGeluLutN;
-        float *lut = blob + kLayout.gelu_lut;
-        for (int i = 0; i <= kGeluLutN; ++i) {
-            double a = 0.0, b = (i == kGeluLutN) ? 1.0 : 0.0;
-            if (i > 0 && i < kGeluLutN) {
-                const double x0 = -L + (i - 1.0 / 16.0) * hh, x1 = x0 + hh, xm = 0.5 * (x0 + x1);
-                b = (g(x1) - g(x0)) / (x1 - x0);
-                a = g(x0) - b * x0;
-                a += 0.5 * (g(xm) - (a + b * xm));
+        const double L = (double)kGeluLutL;
+        auto uniform_table = [&](float *lut, int N) {
+            const double hh = 2.0 * L / N;
+            for (int i = 0; i <= N; ++i) {
+                double a = 0.0, b = (i == N) ? 1.0 : 0.0;
+                if (i > 0 && i < N) {
+                    const double x0 = -L + (i - 1.0 / 16.0) * hh, x1 = x0 + hh, xm = 0.5 * (x0 + x1);
+                    b = (g(x1) - g(x0)) / (x1 - x0);
+                    a = g(x0) - b * x0;
+                    a += 0.5 * (g(xm) - (a + b * xm));
+                }
+                lut[2 * i] = (float)a;
+                lut[2 * i + 1] = (float)b;
             }
-            lut[2 * i] = (float)a;
-            lut[2 * i + 1] = (float)b;
-        }
+        };
+        uniform_table(blob + kLayout.gelu_lut, kGeluLutN);
+        uniform_table(blob + kLayout.gelu_lut2, kGeluLut2N);
         // E(a) = a erf(a / sqrt 2) / 2 over a = |x|: entry k * M + j covers a in [2^k (1 + j / M) - 1, + 2^k / M)
         auto E = [](double a) { return 0.5 * a * erf(a * 0.70710678118654752440); };
         float *lg = blob + kLayout.gelu_log;

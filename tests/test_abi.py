@@ -164,3 +164,13 @@ def test_gelu_chord_tables(lib):
     e = log[idx, 1].astype(np.float32) * np.abs(x) + log[idx, 0].astype(np.float32)
     got = f32(0.5) * x + e.astype(np.float32)
     assert np.abs(got - ref).max() < 1.2e-6
+    # stage-2 block kernel (stage2_f16.h): the uniform table with 2048 intervals, same index arithmetic
+    n2 = 2048
+    o2 = o_log + (2 * (3 * m_log + 1) + 63) // 64 * 64
+    uni2 = blob[o2:o2 + 2 * (n2 + 1)].reshape(-1, 2)
+    assert o2 + 2 * (n2 + 1) <= blob.size
+    t = (y * f32(8.0 * n2) + f32(12582912.0)).astype(np.float32)
+    idx = (t.view(np.uint32) & np.uint32(0x7FF8)) >> 3
+    assert idx.max() == n2 and idx.min() == 0
+    got = uni2[idx, 0].astype(np.float32) + uni2[idx, 1].astype(np.float32) * x
+    assert np.abs(got - ref).max() < 2.4e-6

@@ -48,17 +48,18 @@ def test_asm_load_kernels_do_not_spill(tmp_path):
     if shutil.which("c++filt") is None:
         pytest.skip("c++filt not available")
     meta = _kernel_metadata(tmp_path)
-    names = [n for n in meta if "stage1_kernel16" in n]
-    assert names, "stage-1 kernels not found in the library"
+    names = [n for n in meta if "stage1_kernel16" in n or "stage2_kernel16" in n]
+    assert names, "persistent stage kernels not found in the library"
     checked = 0
     for n in names:
         dem = subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip()
         m = re.search(r"stage1_kernel16<(\d), (true|false)>", dem)
-        assert m, dem
-        if m.group(2) == "false" and m.group(1) in ("0", "1"):       # float input, counted waits
+        m2 = re.search(r"stage2_kernel16<(\d)>", dem)
+        assert m or m2, dem
+        if (m and m.group(2) == "false" and m.group(1) in ("0", "1")) or (m2 and m2.group(1) in ("0", "1")):   # counted waits
             assert meta[n]["vgpr_spill_count"] == 0 and meta[n]["private_segment_fixed_size"] == 0, (dem, meta[n])
             checked += 1
-    assert checked == 2
+    assert checked == 4
 
 
 def test_hand_counted_vmcnt_waits_cover_their_loads():
@@ -83,6 +84,17 @@ def test_hand_counted_vmcnt_waits_cover_their_loads():
         assert checked == (4 if grid else 10), (name, checked)         # 4 pixel loads | 8 u' fragments + 2 pixel loads
         assert all(young >= n for n, young in margins), margins
         assert {n for n, _ in margins} == ({8} if grid else {2, 8}), margins
+    # the stage-2 kernels (stage2_f16.h): grid = 4 input-fragment loads behind 8 u' stores; block = 4 chunks of 8 weight
+    # loads + 8 u' fragments + 4 input fragments, waits at 20 / 20 / 8 / 0
+    kernels = va.disassemble(_lib.LIB_PATH, r"stage2_kernel16ILi[01]E")
+    assert len(kernels) == 2, list(kernels)
+    for name, ins in kernels.items():
+        problems, checked, margins = va.audit(ins)
+        assert not problems, (name, problems)
+        grid = "ILi0E" in name
+        assert checked == (4 if grid else 44), (name, checked)
+        assert all(young >= n for n, young in margins), margins
+        assert {n for n, _ in margins} == ({8} if grid else {0, 8, 20}), margins
 
 
 def test_table_gelu_kernels_have_no_static_lds(tmp_path):
@@ -91,8 +103,8 @@ def test_table_gelu_kernels_have_no_static_lds(tmp_path):
     while the kernel has no static __shared__ allocation (those come first).  Also: none of them may spill -- a spilled
     address or pair register between the asm blocks would be a scratch access the hand-placed waits do not cover."""
     meta = _kernel_metadata(tmp_path)
-    names = [n for n in meta if "stage1_kernel16" in n or "stage_cs_kernel16" in n]
-    assert len(names) >= 6 + 8, names
+    names = [n for n in meta if "stage1_kernel16" in n or "stage2_kernel16" in n or "stage_cs_kernel16" in n]
+    assert len(names) >= 6 + 3 + 5, names                  # stage 1: 3 modes x 2 inputs; stage 2: 3 modes; stages 3-4: 3 + 2
     for n in names:
         assert meta[n]["group_segment_fixed_size"] == 0, (n, meta[n])
         assert meta[n]["vgpr_spill_count"] == 0, (n, meta[n])
