@@ -183,7 +183,7 @@ __device__ __forceinline__ void s2_poll(unsigned addr, unsigned target) {
 //          after conv0 has consumed them, request group i+1's into the same registers.
 //   block: the input fragments of group i+1 are requested late in group i and are covered by that group's last wait;
 //          RSHMAG.dense2's weights stream in four chunks of 8 loads through two register sets, the u' rows (8 loads) are
-//          requested between them; see the waits in the loop body, each annotated with what is younger.
+//          requested in front of the first; see the waits in the loop body, each annotated with what is younger.
 template <int MODE>
 __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(StageArgs A) {
     constexpr int C = kS2C, NW = s2_waves<MODE>(), NTHR = NW * 64, NP = NW / 2;
@@ -192,6 +192,8 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
     static_assert(kFmt32[1] && !kFmt32[2], "stage 2 reads and writes 32x32 fragments; its output feeds the 16x16 kernels of stage 3");
     static_assert(NW % 2 == 0, "waves come in pairs");
     using M = S2Map<MODE>;
+    constexpr int STAMP_KID = 2 + BM; (void)STAMP_KID;           // (diagnostic build only: tools/stamps_s2.py)
+    STAMP_DECL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *par = reinterpret_cast<float *>(smem_raw + M::par);
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
                 store_frag_px(A.out, opix, C, n & 1, h + 2 * ((n >> 3) & 1), o);
             }
         } else {
+        STAMP(0);
         // ---- x0 = relu(conv0(X)) from the prefetched fragments; then the next group's are requested ----
         if constexpr (MODE == 0)
             asm volatile(BALF_S2_WAIT(8) : "+v"(nx[0].hi), "+v"(nx[0].lo), "+v"(nx[1].hi), "+v"(nx[1].lo)::"memory");
@@ -395,15 +398,19 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
         }
         HL b[4];
         s2_ln_split(x0, b);
+        STAMP(1);   // wait for the input, conv0, relu, LN + split
         f16v z[2];                                               // u (grid) / v (block): kept for the branch residual
         s2_bias(z, par + kS2pQ1B, h);
         s2_linear<4>(z, wl + M::q1, b);
         s2_gelu<MODE>(z);
+        STAMP(2);   // dense1 half + GELU
         s2_ln_split(z, b);
+        STAMP(3);   // LN + split
         f16v ga[2];
         s2_bias(ga, par + kS2pD1B, h);
         s2_linear<4>(ga, wl + M::d1, b);
         s2_gelu<MODE>(ga);
+        STAMP(4);   // branch dense1 (a half) + GELU
         {
             f16v gb[2];
             s2_bias(gb, par + kS2pD1B + C, h);
@@ -411,6 +418,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
             s2_gelu<MODE>(gb);
             float rstd, shift;
             s2_ln_stats(gb, rstd, shift);                        // gating LayerNorm (affine) over the pixel's 64 channels
+            STAMP(5);   // branch dense1 (b half) + GELU + LN statistics
             // write offsets of the lane's token (column t = 32 w + n) in channel rows 4 h + r (+ 8 g: an immediate)
             int wo[4];
 #pragma unroll
@@ -421,6 +429,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
             for (int rt = 0; rt < 2; ++rt) {
                 // one 32-channel row tile per pass through the pair's token tile
                 s2_poll(peer_flags + 4, pass + rt);             // the partner has read the previous pass
+                if (rt == 0) STAMP(6); else STAMP(10);           // waiting for the partner's reads
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const f4 gg = *reinterpret_cast<const f4 *>(par + kS2pGlnG + 32 * rt + 8 * gq + 4 * h);
@@ -439,7 +448,9 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
                     }
                 }
                 s2_post(my_flags, pass + rt + 1);                // written (LDS instructions of a wave execute in order)
+                if (rt == 0) STAMP(7); else STAMP(11);           // gating LN + split + tile writes
                 s2_poll(peer_flags, pass + rt + 1);              // ... and the partner's half is there too
+                if (rt == 0) STAMP(8); else STAMP(12);           // waiting for the partner's writes
                 HL a[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -463,20 +474,23 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ga[rt][r] *= m[r];
+                if (rt == 0) STAMP(9); else STAMP(13);           // tile reads, mix, gate
             }
             pass += 2;
         }
-        s2_split(ga, b);
         f16v o[2];
         if constexpr (MODE == 0) {
+            s2_split(ga, b);
             s2_bias(o, par + kS2pD2B, h);
             s2_linear<4>(o, wl + M::d2, b);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[rt][r] += z[rt][r];
+            STAMP(14);  // split + dense2 + residual
 #pragma unroll
             for (int s = 0; s < 4; ++s) store_frag32(A.U, pix, C, s, h, s1_split8(o[s >> 1], s & 1));
+            STAMP(15);  // split + u' store
         } else {
             // ---- block branch: RSHMAG.dense2 over cat[u', v'] with its weights streamed from L2 ----
             // chunk c = (row tile c & 1, K-steps 4 (1 - (c >> 1)) ..+3): c0, c1 = the v' half (K-steps 4-7), c2, c3 = the u' half
@@ -497,18 +511,11 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
 #define BALF_S2_QWAIT(SET, N, ...)                                                                                           \
     asm volatile(BALF_S2_WAIT(N) : "+v"(wq[SET][0].hi), "+v"(wq[SET][0].lo), "+v"(wq[SET][1].hi), "+v"(wq[SET][1].lo),       \
                  "+v"(wq[SET][2].hi), "+v"(wq[SET][2].lo), "+v"(wq[SET][3].hi), "+v"(wq[SET][3].lo) __VA_ARGS__::"memory")
-            s2_bias(o, par + kS2pD2B, h);
-            s2_linear<4>(o, wl + M::d2, b);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[rt][r] += z[rt][r];
-            // (requested here, not before dense2: with z, the gated branch, dense2's accumulators and weight fragments live
-            // there, 64 more registers spill)
-            BALF_S2_QLOAD(0, 0);
-            BALF_S2_QLOAD(1, 1);
-            // the u' rows of the lane's pixel (written by the grid kernel just before: L2 / Infinity Cache), then the next
-            // group's input fragments
+            // The u' rows of the lane's pixel (written by the grid kernel just before: L2 / Infinity Cache) are requested BEFORE
+            // dense2, whose split + 24 MFMAs cover most of their round trip; the weight chunks and the next group's input
+            // fragments behind it (with z, the gated branch, dense2's accumulators and weight fragments live, 32 more
+            // registers there spill).  The phase stamps showed 2.5 k of a group's 49 k cycles waiting for u' when it was
+            // requested after dense2.
             HL ub[4];
             {
                 const unsigned uo = (unsigned)(g.y * W + g.x) * 256u + (unsigned)h * 16u;
@@ -521,24 +528,39 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
                                "=&v"(ub[3].hi), "=&v"(ub[3].lo)
                              : "v"(uo), "s"(ubase) : "memory");
             }
+            s2_split(ga, b);
+            s2_bias(o, par + kS2pD2B, h);
+            s2_linear<4>(o, wl + M::d2, b);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[rt][r] += z[rt][r];
+            STAMP(14);  // requests, split + dense2 + residual
+            BALF_S2_QLOAD(0, 0);
+            BALF_S2_QLOAD(1, 1);
             issue_in(geo(nxt), nx);
             s2_split(o, b);                                      // v'
             f16v x1[2];
             s2_bias(x1, par + kS2pQ2B, h);
-            BALF_S2_QWAIT(0, 20);                                // c0 has landed; younger: c1 8 + u' 8 + next input 4
+            STAMP(15);  // requests, split of v'
+            BALF_S2_QWAIT(0, 12);                                // c0 has landed (and u', older); younger: c1 8 + next input 4
+            STAMP(16);  // waiting for the first weight chunk
             s2_linear_regs(x1[0], wq[0], b);
             __builtin_amdgcn_sched_barrier(0);                   // c0's MFMAs are issued: its registers take c2
             BALF_S2_QLOAD(0, 2);
-            BALF_S2_QWAIT(1, 20);                                // c1; younger: u' 8 + next input 4 + c2 8
+            BALF_S2_QWAIT(1, 12);                                // c1; younger: next input 4 + c2 8
             s2_linear_regs(x1[1], wq[1], b);
             __builtin_amdgcn_sched_barrier(0);
             BALF_S2_QLOAD(1, 3);
-            // u' and c2 (the next input's fragments, older than c2, have landed with them); younger: c3 8
+            // c2 (u' and the next input's fragments, older, have landed before it); younger: c3 8
+            STAMP(17);  // v' half of RSHMAG.dense2
             BALF_S2_QWAIT(0, 8, , "+v"(ub[0].hi), "+v"(ub[0].lo), "+v"(ub[1].hi), "+v"(ub[1].lo), "+v"(ub[2].hi), "+v"(ub[2].lo),
                           "+v"(ub[3].hi), "+v"(ub[3].lo), "+v"(nx[0].hi), "+v"(nx[0].lo), "+v"(nx[1].hi), "+v"(nx[1].lo));
+            STAMP(18);  // waiting for u' and the third chunk
             s2_linear_regs(x1[0], wq[0], ub);
             BALF_S2_QWAIT(1, 0);                                 // c3
             s2_linear_regs(x1[1], wq[1], ub);
+            STAMP(19);  // u' half
 #undef BALF_S2_QLOAD
 #undef BALF_S2_QWAIT
             // x1 = . + x0, stored in REGISTER ORDER for the tail kernel (same group and lane geometry): per wave half 8 KB =
@@ -553,11 +575,13 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
                     *reinterpret_cast<f4 *>(rp + ((rt * 4 + gq) * 64 + lane) * 4) =
                         f4{x1[rt][4 * gq], x1[rt][4 * gq + 1], x1[rt][4 * gq + 2], x1[rt][4 * gq + 3]};
             }
+            STAMP(20);  // residual + x1 store
             s2_ln_split(x1, b);
             f16v m1[2];
             s2_bias(m1, par + kS2pR1B, h);
             s2_linear<4>(m1, wl + M::r1, b);
             lrelu32(m1);
+            STAMP(21);  // LN + split + conv1 + lrelu
             // conv2 is linear: its channel means follow from those of its input (SE kernel); the tail kernel recomputes the
             // branch from x1.  Channel sums over the wave's 32 pixels (fixed order), one partial row per wave half: the two
             // 16-lane rows of a lane half as a reduce-scatter (one row swap serves registers r and r + 8), then the row.
@@ -585,6 +609,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
                     *reinterpret_cast<f4 *>(pp + 8) = f4{cs[4], cs[5], cs[6], cs[7]};
                 }
             }
+            STAMP(22);  // channel sums
         }
         }   // !TAIL
     }

@@ -29,6 +29,9 @@ def slot_of(kernel: str):
     m = re.match(r"stage1_kernel16<(\d)", k)
     if m:
         return "stage1_pool" if m.group(1) == "2" else "stage1_%s_branch" % ("grid" if m.group(1) == "0" else "block")
+    m = re.match(r"stage2_kernel16<(\d)", k)
+    if m:
+        return "stage2_pool" if m.group(1) == "2" else "stage2_%s_branch" % ("grid" if m.group(1) == "0" else "block")
     m = re.match(r"stage_cs_kernel16<(\d+), \d+, (\d)>", k)
     if m:
         st = [32, 64, 128, 256].index(int(m.group(1))) + 1
@@ -75,8 +78,8 @@ for prec in ("fp16", "fp32"):
              "fetch_kib_raw": c.get("FETCH_SIZE", 0.0), "write_kib": c.get("WRITE_SIZE", 0.0)}
         if c.get("SQ_WAVE_CYCLES"):
             simd_cycles = 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
-            # (stage 1 of the split-f16 path issues v_mfma_f32_32x32x16_f16: twice the MACs and cycles of a 16x16x32)
-            mf = c.get("SQ_INSTS_MFMA", 0.0) * (2.0 if prec == "fp16" and s.startswith("stage1_") and not s.endswith("_se") else 1.0)
+            # (stages 1-2 of the split-f16 path issue v_mfma_f32_32x32x16_f16: twice the MACs and cycles of a 16x16x32)
+            mf = c.get("SQ_INSTS_MFMA", 0.0) * (2.0 if prec == "fp16" and s.startswith(("stage1_", "stage2_")) and not s.endswith("_se") else 1.0)
             d.update({"waves": c["SQ_WAVES"], "valu_insts": c["SQ_INSTS_VALU"], "mfma_insts": c.get("SQ_INSTS_MFMA", 0.0),
                       "issue_share": (c["SQ_INSTS_VALU"] * 2.6 + mf * mfma_cycles) / simd_cycles,
                       "wave_wait_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
@@ -86,6 +89,24 @@ for prec in ("fp16", "fp32"):
                       "valu_busy_share": 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles,
                       "mfma_busy_share": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles,
                       "gpu_cycles": c["GRBM_GUI_ACTIVE"] / 8.0})
+            # LDS and L2 activity (round 4): instructions, array-busy and bank-conflict cycles per SIMD-cycle-equivalent of the
+            # CU's one LDS (cycles / CU cycles), L2 requests and hit rate, L1 -> L2 read requests (64 B each)
+            cu_cycles = 256.0 * c["GRBM_GUI_ACTIVE"] / 8.0
+            for key, name in (("SQ_INSTS_LDS", "lds_insts"), ("SQ_INSTS_VMEM", "vmem_insts"), ("SQ_INSTS_SALU", "salu_insts")):
+                if key in c:
+                    d[name] = c[key]
+            if "SQ_LDS_IDX_ACTIVE" in c:
+                d["lds_array_busy_share"] = c["SQ_LDS_IDX_ACTIVE"] / cu_cycles
+            if "SQ_LDS_BANK_CONFLICT" in c:
+                d["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / cu_cycles
+            if "SQ_ACTIVE_INST_LDS" in c:
+                d["lds_inst_active_share"] = 4.0 * c["SQ_ACTIVE_INST_LDS"] / simd_cycles
+            if "TCC_REQ_sum" in c:
+                d["l2_requests"] = c["TCC_REQ_sum"]
+                if c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0) > 0:
+                    d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+            if "TCP_TCC_READ_REQ_sum" in c:
+                d["l1_to_l2_read_requests"] = c["TCP_TCC_READ_REQ_sum"]
         slots[s] = d
     res[prec] = slots
 json.dump({"command": "tools/pmc_profile.sh: per precision three rocprofv3 --kernel-trace --pmc passes of "

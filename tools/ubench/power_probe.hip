@@ -4,6 +4,8 @@
 // while tools/power_probe.sh samples rocm-smi; the program prints the achieved instruction rate.
 //   mode 0: v_mfma_f32_16x16x32_f16   1: v_mfma_f32_32x32x16_f16   2: v_fma_f32   3: v_exp_f32   4: 1 MFMA(16x16x32) : 6 fma
 //   5: v_pk_fma_f32   6: the operand split of a pair
+//   (round 4: data movement)  7: ds_read_b128 from LDS (1 KB per wave-instruction)   8: global_load_dwordx4 from an L2-resident
+//   1 MB window (L1 thrashed: every CU sweeps 64 KB per iteration)   9: the same from a 4 GB buffer (HBM)
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/power_probe.hip -o tools/ubench/power_probe
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -12,6 +14,34 @@
 typedef float f4x __attribute__((ext_vector_type(4)));
 typedef float f16x __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+template <int MODE>
+__global__ __launch_bounds__(512) void kmem(float *out, const char *buf, unsigned long long span, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
+    for (int i = threadIdx.x; i < 65536 / 16; i += 512) reinterpret_cast<uint4 *>(lds)[i] = make_uint4(i, i + 1, i + 2, i + 3);
+    __syncthreads();
+    f4x acc = {0.f, 0.f, 0.f, 0.f};
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 7) {
+            f4x v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f4x *>(lds + ((j * 8 + wave) * 1024 + lane * 16));
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        } else {
+            // 8 loads of 1 KB per wave and iteration; the workgroup sweeps 64 KB per iteration, `span` bytes in all
+            const unsigned long long base = ((unsigned long long)blockIdx.x * 65536ull * 977ull + (unsigned long long)it * 65536ull) % span;
+            f4x v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f4x *>(buf + (base + (j * 8 + wave) * 1024 + lane * 16) % span);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+}
 
 template <int MODE>
 __global__ __launch_bounds__(512) void k(float *out, int iters) {
@@ -74,9 +104,18 @@ int main(int argc, char **argv) {
     const double secs = argc > 2 ? atof(argv[2]) : 4.0;
     float *out;
     (void)hipMalloc(&out, 256 * 512 * 4);
-    const int iters = 20000;
+    const int iters = mode >= 7 ? 4000 : 20000;
+    char *buf = nullptr;
+    const unsigned long long span = mode == 9 ? (4ull << 30) : (1ull << 20);
+    if (mode >= 8) {
+        (void)hipMalloc(&buf, span);
+        (void)hipMemset(buf, 1, span);
+    }
     auto launch = [&]() {
         switch (mode) {
+            case 7: hipLaunchKernelGGL(kmem<7>, dim3(256), dim3(512), 0, 0, out, buf, span, iters); break;
+            case 8: hipLaunchKernelGGL(kmem<8>, dim3(256), dim3(512), 0, 0, out, buf, span, iters); break;
+            case 9: hipLaunchKernelGGL(kmem<9>, dim3(256), dim3(512), 0, 0, out, buf, span, iters); break;
             case 0: hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, out, iters); break;
             case 1: hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, out, iters); break;
             case 2: hipLaunchKernelGGL(k<2>, dim3(256), dim3(512), 0, 0, out, iters); break;
@@ -98,9 +137,12 @@ int main(int argc, char **argv) {
         el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } while (el < secs);
     // per iteration and wave: 8 MFMA(16x16x32) | 4 MFMA(32x32x16) | 128 fma | 32 exp | 8 MFMA + 48 fma;  2048 waves
-    const double per_iter[7] = {8, 4, 128, 32, 8, 64, 32};
+    const double per_iter[10] = {8, 4, 128, 32, 8, 64, 32, 8, 8, 8};
     const double rate = n * (double)iters * per_iter[mode] * 2048 / el;
-    const char *what[7] = {"MFMA16x16x32", "MFMA32x32x16", "v_fma_f32", "v_exp_f32", "MFMA16x16x32 (+6 fma each)", "v_pk_fma_f32", "operand-split pairs (4 instr + 2 adds each)"};
-    printf("mode %d: %.3e %s wave-instructions/s over %.1f s (%.2f per SIMD per us)\n", mode, rate, what[mode], el, rate / 1024 / 1e6);
+    const char *what[10] = {"MFMA16x16x32", "MFMA32x32x16", "v_fma_f32", "v_exp_f32", "MFMA16x16x32 (+6 fma each)", "v_pk_fma_f32", "operand-split pairs (4 instr + 2 adds each)",
+                            "ds_read_b128 (1 KB each)", "global_load_dwordx4 from L2 (1 KB each)", "global_load_dwordx4 from HBM (1 KB each)"};
+    printf("mode %d: %.3e %s wave-instructions/s over %.1f s (%.2f per SIMD per us)", mode, rate, what[mode], el, rate / 1024 / 1e6);
+    if (mode >= 7) printf("  = %.2f TB/s", rate * 1024 / 1e12);
+    printf("\n");
     return 0;
 }
