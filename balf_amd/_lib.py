@@ -29,6 +29,7 @@ PROTOTYPES = {
     "balf_packed_weights_bytes": (_sz, [_i]),
     "balf_pack_weights": (_i, [C.POINTER(_vp), _i, _i, _vp, _sz]),
     "balf_forward_workspace_bytes": (_sz, [_i, _i, _i]),
+    "balf_forward_micro_batch": (_i, [_i, _i, _i]),
     "balf_forward": (_i, [_vp, _i, _fp, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
     "balf_forward_u8": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
     "balf_forward_stage_view_numel": (_sz, [_i, _i, _i, _i]),

@@ -399,6 +399,12 @@ struct HeadArgs {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+#ifndef BALF_MB_PIXELS
+// padded input pixels per micro-batch: 16 images at 1088x1920 (14.8 GB of workspace).  Round 4: 8 -> 16 images per launch,
+// +1 % on 32 x 1080p (the persistent kernels stage ~100 KB of weights per CU at every launch and end on a partial round of
+// groups; 32 per launch buys nothing more).  balf_forward_micro_batch() reports it.
+#define BALF_MB_PIXELS (32L * 1024 * 1024)
+#endif
 struct Plan {
     int mb;                 // images per micro-batch
     size_t off_U, off_T, off_R, off_X[3], off_partial, off_chunk, off_scale, total;
@@ -407,7 +413,7 @@ struct Plan {
 inline Plan make_plan(int B, int Hp, int Wp) {
     Plan p{};
     const long px = (long)Hp * Wp;
-    long mb = (16L * 1024 * 1024) / px;                // <= 16.8 Mpx of stage-1 activations in flight
+    long mb = (long)BALF_MB_PIXELS / px;               // <= 33.5 Mpx of stage-1 activations in flight
     if (mb < 1) mb = 1;
     if (mb > B) mb = B;
     p.mb = (int)mb;

@@ -466,6 +466,11 @@ extern "C" size_t balf_forward_workspace_bytes(int B, int Hp, int Wp) {
     return balf::make_plan(B, Hp, Wp).total;
 }
 
+extern "C" int balf_forward_micro_batch(int B, int Hp, int Wp) {
+    if (B <= 0 || Hp <= 0 || Wp <= 0 || Hp % 64 || Wp % 64) return 0;
+    return balf::make_plan(B, Hp, Wp).mb;
+}
+
 static int forward_common(const void *packed_dev, int precision, const float *x_nchw_dev, const balf::InputU8 &u8, int B,
                           int Hp, int Wp, float *logits_dev, float *prob_dev, void *workspace_dev,
                           size_t workspace_bytes, void *stream) {

@@ -63,6 +63,7 @@ def _newest_pmc_profile():
 
 
 PMC_PROFILE = _newest_pmc_profile()
+PMC_IMAGES_PER_LAUNCH = 16         # the shape the PMC passes are taken on (tools/pmc_run.sh: one micro-batch of 1088x1920)
 C_STAGE = [32, 64, 128, 256]
 CIN_STAGE = [3, 32, 64, 128]
 
@@ -114,7 +115,7 @@ def kernel_flops_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
 def pmc_profile(precision: str, mb: int, hp: int, wp: int):
     """The committed PMC passes (profiles/rN_pmc.json of the newest round, tools/pmc_json.py): per profile slot, HBM bytes per launch and the
     issue-slot accounting; None when they do not cover this shape."""
-    if not (os.path.isfile(PMC_PROFILE) and mb == 8 and (hp, wp) == (1088, 1920)):
+    if not (os.path.isfile(PMC_PROFILE) and mb == PMC_IMAGES_PER_LAUNCH and (hp, wp) == (1088, 1920)):
         return None
     try:
         return json.load(open(PMC_PROFILE))["slots"][precision]
@@ -553,7 +554,7 @@ def main():
     def summarize(precision, dt_, prof_, steps, b=b, hp=hp, wp=wp):
         """images/s + the roofline of the dominant kernel against both roofs and the issue limit (b, hp, wp: the
         configuration the profile was taken on; default: the headline one)."""
-        mb = max(1, min(b, 16 * 1024 * 1024 // (hp * wp)))          # images per launch (make_plan in det_common.h)
+        mb = _balf_lib.lib().balf_forward_micro_batch(b, hp, wp)      # images per launch (make_plan in det_common.h)
         name, (ms, n_launch) = max(prof_.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / n_launch
         flops = kernel_flops_per_launch(name, mb, hp, wp)

@@ -82,6 +82,9 @@ int balf_pack_weights(const float *const *tensors, int n_tensors, int precision,
  * prob_dev   : [B,Hp,Wp] fp32 score map (softmax over 65, dustbin dropped, pixel-shuffled)
  * workspace  : balf_forward_workspace_bytes(B,Hp,Wp) bytes, 256-byte aligned */
 size_t balf_forward_workspace_bytes(int B, int Hp, int Wp);
+/* Images per launch: the forward walks a batch in micro-batches of this many images (the workspace holds one micro-batch:
+ * 16 images at 1088x1920, more at smaller sizes; B if the batch is smaller).  0: bad arguments. */
+int balf_forward_micro_batch(int B, int Hp, int Wp);
 int balf_forward(const void *packed_dev, int precision, const float *x_nchw_dev, int B, int Hp, int Wp,
                  float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
                  void *stream);
@@ -103,8 +106,8 @@ int balf_forward_u8(const void *packed_dev, int precision, const unsigned char *
  *               fragments in the workspace; the view adds the halves);
  *   stage 4     x2 = t * s + x1 + x0 of down4 BEFORE its conv2 (:239-241; conv2 runs inside the head kernel and its output
  *               never exists in memory): [B, Hp/8, Wp/8, 256] -- apply down4.conv2 to compare with the reference's down4.
- * Only the last micro-batch of a forward is resident in the workspace: B must not exceed it (BALF_ERR_ARG otherwise; 8
- * images at 1088x1920, more at smaller sizes).  balf_forward_stage_view_numel = elements of out_dev (0: bad arguments). */
+ * Only the last micro-batch of a forward is resident in the workspace: B must not exceed it (BALF_ERR_ARG otherwise;
+ * balf_forward_micro_batch: 16 images at 1088x1920, more at smaller sizes).  balf_forward_stage_view_numel = elements of out_dev (0: bad arguments). */
 size_t balf_forward_stage_view_numel(int B, int Hp, int Wp, int stage);
 int balf_forward_stage_view(int precision, const void *workspace_dev, size_t workspace_bytes, int B, int Hp, int Wp, int stage,
                             float *out_dev, void *stream);

@@ -56,7 +56,11 @@ def test_state_table_matches_reference_state_dict(lib):
 def test_size_queries_and_argument_checks(lib):
     assert lib.balf_forward_workspace_bytes(1, 64, 64) > 0
     assert lib.balf_forward_workspace_bytes(1, 100, 64) == 0          # not a multiple of 64
-    assert lib.balf_forward_workspace_bytes(32, 1088, 1920) == lib.balf_forward_workspace_bytes(8, 1088, 1920)
+    # the workspace holds one micro-batch (16 images at 1088x1920), whatever the batch
+    assert lib.balf_forward_workspace_bytes(32, 1088, 1920) == lib.balf_forward_workspace_bytes(16, 1088, 1920)
+    assert lib.balf_forward_workspace_bytes(8, 1088, 1920) < lib.balf_forward_workspace_bytes(16, 1088, 1920)
+    assert lib.balf_forward_micro_batch(32, 1088, 1920) == 16 and lib.balf_forward_micro_batch(5, 1088, 1920) == 5
+    assert lib.balf_forward_micro_batch(1, 100, 64) == 0
     assert lib.balf_nms_topk_workspace_bytes(2, 480, 640, 1000) >= 2 * 480 * 640 * 8
     assert lib.balf_packed_weights_bytes(0) >= 1280728 * 4
     # host-side validation happens before anything touches a device

@@ -146,16 +146,19 @@ def test_batch_invariance_and_determinism(model):
 
 @pytest.mark.parametrize("which", ["fp32", "fp16"])
 def test_micro_batch_boundary_is_invisible(model, model16, which):
-    """balf_forward walks the batch in micro-batches (8 images at 1088x1920): image 8 of a batch of 9 lives in
-    the second micro-batch and must come out exactly as when it is run alone."""
+    """balf_forward walks the batch in micro-batches (balf_forward_micro_batch: 16 images at 1088x1920): the last image of a
+    batch of one micro-batch + 1 lives in the second micro-batch and must come out exactly as when it is run alone."""
+    from balf_amd import _lib
     m = model if which == "fp32" else model16
+    mb = _lib.lib().balf_forward_micro_batch(64, 1088, 1920)
+    assert mb == 16 and _lib.lib().balf_forward_micro_batch(3, 1088, 1920) == 3
     g = torch.Generator(device="cpu").manual_seed(5)
-    x = torch.rand(9, 3, 1088, 1920, generator=g).to("cuda:0")
+    x = torch.rand(mb + 1, 3, 1088, 1920, generator=g).to("cuda:0")
     with torch.inference_mode():
         full = m(x, want_logits=False)["prob"]
-        last = m(x[8:9].contiguous(), want_logits=False)["prob"]
+        last = m(x[mb:mb + 1].contiguous(), want_logits=False)["prob"]
         first = m(x[0:1].contiguous(), want_logits=False)["prob"]
-    assert torch.equal(full[8:9], last) and torch.equal(full[0:1], first)
+    assert torch.equal(full[mb:mb + 1], last) and torch.equal(full[0:1], first)
 
 
 def test_forward_vs_oracle_fp64_larger(model):

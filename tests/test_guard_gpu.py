@@ -4,7 +4,7 @@ The library writes through hand-computed offsets into buffers the caller sizes f
 documented output shapes (include/balf_hip.h); the Python wrappers hand it a cached, possibly over-sized workspace, so an
 overrun of a few KB -- or a read of a slot nobody wrote -- is invisible to the parity tests.  Here every buffer is carved out
 of an allocation with 1 MiB of patterned guard on both sides and passed with EXACTLY the documented size, through the C ABI,
-at every BASELINE shape and at batch sizes that end in a partial micro-batch (1, 9, 33); and the forward is run on a
+at every BASELINE shape and at batch sizes that end in a partial micro-batch (1, 9, 33: the micro-batch is 16 images at 1088x1920); and the forward is run on a
 workspace full of NaN bit patterns against one full of zeros: the outputs must be bit-identical."""
 import ctypes as C
 
@@ -131,10 +131,10 @@ def test_nms_topk_and_greedy_stay_inside_their_buffers(h, w, k, b):
 
 
 @pytest.mark.parametrize("precision", ["fp16", "fp32"])
-@pytest.mark.parametrize("b,hp,wp", [(2, 128, 192), (9, 512, 640), (9, 1088, 1920)])
+@pytest.mark.parametrize("b,hp,wp", [(2, 128, 192), (9, 512, 640), (17, 1088, 1920)])
 def test_forward_does_not_read_stale_workspace(blobs, precision, b, hp, wp):
     """Every workspace slot is written before it is read: a workspace full of 0xFF bytes (NaN as fp32 and as f16) gives the
-    bits a zeroed one gives.  9 x 1088x1920 is two micro-batches: the second one runs on the first one's leftovers too."""
+    bits a zeroed one gives.  17 x 1088x1920 is two micro-batches: the second one runs on the first one's leftovers too."""
     l = _lib.lib()
     blob, prec = blobs[precision]
     x = torch.rand((b, 3, hp, wp), device=DEV)

@@ -85,13 +85,14 @@ def test_stage_view_rejects_what_is_not_resident():
         m(cases.forward_input(1, 64, 64, 1).to("cuda:0"))
     with pytest.raises(ValueError):
         m.stage_view(1, 60, 64)
-    # 9 x 1088x1920 runs as two micro-batches (8 + 1): the first one's activations are gone when the call returns
+    # one image more than a micro-batch runs as two launches: the first one's activations are gone when the call returns
     from balf_amd import _lib
     l = _lib.lib()
-    assert l.balf_forward_stage_view_numel(9, 1088, 1920, 1) > 0
-    ws = torch.empty(l.balf_forward_workspace_bytes(9, 1088, 1920), dtype=torch.uint8, device="cuda:0")
+    nb = l.balf_forward_micro_batch(64, 1088, 1920) + 1
+    assert l.balf_forward_stage_view_numel(nb, 1088, 1920, 1) > 0
+    ws = torch.empty(l.balf_forward_workspace_bytes(nb, 1088, 1920), dtype=torch.uint8, device="cuda:0")
     out = torch.empty(16, device="cuda:0")
-    assert l.balf_forward_stage_view(1, ws.data_ptr(), ws.numel(), 9, 1088, 1920, 1, out.data_ptr(), None) == -1
+    assert l.balf_forward_stage_view(1, ws.data_ptr(), ws.numel(), nb, 1088, 1920, 1, out.data_ptr(), None) == -1
     del ws
     with pytest.raises(BalfHipError):
-        m.stage_view(9, 1088, 1920)
+        m.stage_view(nb, 1088, 1920)

@@ -110,7 +110,7 @@ for prec in ("fp16", "fp32"):
         slots[s] = d
     res[prec] = slots
 json.dump({"command": "tools/pmc_profile.sh: per precision three rocprofv3 --kernel-trace --pmc passes of "
-                      "`python3 bench.py --steps 1 --warmup 1 --batch-per-gpu 8 --cpu-images 0 --other-steps 0 --other-configs 0` "
-                      "(1088x1920, 8 images per launch): SQ counters + GRBM_GUI_ACTIVE, FETCH_SIZE, WRITE_SIZE",
+                      "`python3 bench.py --steps 1 --warmup 1 --batch-per-gpu 16 --cpu-images 0 --other-steps 0 --other-configs 0` "
+                      "(1088x1920, 16 images per launch): SQ counters + GRBM_GUI_ACTIVE, FETCH_SIZE, WRITE_SIZE",
            "definitions": __doc__, "slots": res}, open(out, "w"), indent=1)
 print(out)

@@ -18,7 +18,7 @@ from oracle import oracle as O                                         # noqa: E
 def plan(b, hp, wp):
     """make_plan of det_common.h"""
     px = hp * wp
-    mb = max(1, min(b, (16 * 1024 * 1024) // px))
+    mb = _lib.lib().balf_forward_micro_batch(b, hp, wp)
     o, off = 0, {}
 
     def take(name, floats):
