@@ -97,6 +97,7 @@ for prec in ("fp16", "fp32"):
                     d[name] = c[key]
             if "SQ_LDS_IDX_ACTIVE" in c:
                 d["lds_array_busy_share"] = c["SQ_LDS_IDX_ACTIVE"] / cu_cycles
+                d["lds_idx_active_cycles"] = c["SQ_LDS_IDX_ACTIVE"]
             if "SQ_LDS_BANK_CONFLICT" in c:
                 d["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / cu_cycles
             if "SQ_ACTIVE_INST_LDS" in c:
