@@ -35,6 +35,9 @@
 #ifndef BALF_HN_STAMPS
 #define BALF_HN_STAMPS 0         // the same in the HardNet kernels (hardnet.hip)
 #endif
+#ifndef BALF_ABLATE_QSTREAM
+#define BALF_ABLATE_QSTREAM 0    // stage-2 block kernel: RSHMAG.dense2's weights are read from LDS (another Linear's tiles) instead of streamed from L2
+#endif
 #ifndef BALF_DEBUG_STOP
 #define BALF_DEBUG_STOP 0        // the f16 forward stops after the stage named by the environment variable BALF_DEBUG_STOP_STAGE (tools/s2_debug.py)
 #endif
@@ -44,7 +47,7 @@
 
 #define BALF_DIAGNOSTIC_BUILD                                                                                      \
     (BALF_ABLATE_GELU || BALF_ABLATE_BARRIER || BALF_ABLATE_LOADLAT || BALF_ABLATE_LUTCOPY || BALF_ABLATE_WSTREAM || \
-     BALF_ABLATE_SPLIT || BALF_DROP_WLO || BALF_STAMPS || BALF_HN_STAMPS || BALF_S1_STRICT || BALF_DEBUG_STOP)
+     BALF_ABLATE_SPLIT || BALF_DROP_WLO || BALF_STAMPS || BALF_HN_STAMPS || BALF_S1_STRICT || BALF_DEBUG_STOP || BALF_ABLATE_QSTREAM)
 #if BALF_DIAGNOSTIC_BUILD && !defined(BALF_ALLOW_DIAGNOSTIC_BUILD)
 #error "a diagnostic switch (csrc/diag.h) is set: pass -DBALF_ALLOW_DIAGNOSTIC_BUILD=1 as well (tools/build_variant.sh does) -- such a library must not ship"
 #endif
@@ -56,4 +59,4 @@
     BALF_DIAG_ITEM(BALF_ABLATE_GELU) BALF_DIAG_ITEM(BALF_ABLATE_BARRIER) BALF_DIAG_ITEM(BALF_ABLATE_LOADLAT)        \
     BALF_DIAG_ITEM(BALF_ABLATE_LUTCOPY) BALF_DIAG_ITEM(BALF_ABLATE_WSTREAM) BALF_DIAG_ITEM(BALF_ABLATE_SPLIT)       \
     BALF_DIAG_ITEM(BALF_DROP_WLO) BALF_DIAG_ITEM(BALF_STAMPS) BALF_DIAG_ITEM(BALF_HN_STAMPS) BALF_DIAG_ITEM(BALF_S1_STRICT) \
-    BALF_DIAG_ITEM(BALF_DEBUG_STOP)
+    BALF_DIAG_ITEM(BALF_DEBUG_STOP) BALF_DIAG_ITEM(BALF_ABLATE_QSTREAM)

@@ -536,11 +536,22 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[rt][r] += z[rt][r];
             STAMP(14);  // requests, split + dense2 + residual
+            f16v x1[2];
+            if constexpr (BALF_ABLATE_QSTREAM) {                 // (timing experiment: what the streaming itself costs)
+                issue_in(geo(nxt), nx);
+                s2_split(o, b);
+                s2_bias(x1, par + kS2pQ2B, h);
+                s2_linear_rt<4>(x1[0], wl + M::d1, b);
+                s2_linear_rt<4>(x1[1], wl + M::d1 + 4 * 2048, b);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ub[0].hi), "+v"(ub[0].lo), "+v"(ub[1].hi), "+v"(ub[1].lo), "+v"(ub[2].hi), "+v"(ub[2].lo),
+                             "+v"(ub[3].hi), "+v"(ub[3].lo), "+v"(nx[0].hi), "+v"(nx[0].lo), "+v"(nx[1].hi), "+v"(nx[1].lo)::"memory");
+                s2_linear_rt<4>(x1[0], wl + M::d1 + 8 * 2048, ub);
+                s2_linear_rt<4>(x1[1], wl + M::d1 + 12 * 2048, ub);
+            } else {
             BALF_S2_QLOAD(0, 0);
             BALF_S2_QLOAD(1, 1);
             issue_in(geo(nxt), nx);
             s2_split(o, b);                                      // v'
-            f16v x1[2];
             s2_bias(x1, par + kS2pQ2B, h);
             STAMP(15);  // requests, split of v'
             BALF_S2_QWAIT(0, 12);                                // c0 has landed (and u', older); younger: c1 8 + next input 4
@@ -560,6 +571,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
             s2_linear_regs(x1[0], wq[0], ub);
             BALF_S2_QWAIT(1, 0);                                 // c3
             s2_linear_regs(x1[1], wq[1], ub);
+            }
             STAMP(19);  // u' half
 #undef BALF_S2_QLOAD
 #undef BALF_S2_QWAIT
