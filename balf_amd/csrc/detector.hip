@@ -462,7 +462,7 @@ int forward_f32(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
 }  // namespace balf
 
 extern "C" size_t balf_forward_workspace_bytes(int B, int Hp, int Wp) {
-    if (B <= 0 || Hp <= 0 || Wp <= 0 || Hp % 64 || Wp % 64) return 0;
+    if (B <= 0 || Hp <= 0 || Wp <= 0 || Hp % 64 || Wp % 64 || (long)Hp * Wp > (1L << 25)) return 0;
     return balf::make_plan(B, Hp, Wp).total;
 }
 
@@ -479,6 +479,9 @@ static int forward_common(const void *packed_dev, int precision, const float *x_
     if (B <= 0 || Hp <= 0 || Wp <= 0) return BALF_ERR_ARG;
     if (Hp % 64 || Wp % 64) return BALF_ERR_SHAPE;
     if ((long)B * Hp * Wp * 32 > 0x7fffffffffL) return BALF_ERR_SHAPE;
+    // the kernels address a pixel's row inside ONE image with 32-bit byte offsets (up to 128 B per stage-1 pixel): 2^25 pixels
+    // per padded image (5792 x 5792) is the limit; it is also what one micro-batch holds (BALF_MB_PIXELS)
+    if ((long)Hp * Wp > (1L << 25)) return BALF_ERR_SHAPE;
     const balf::Plan pl = balf::make_plan(B, Hp, Wp);
     if (workspace_bytes < pl.total) return BALF_ERR_WORKSPACE;
     const float *blob = static_cast<const float *>(packed_dev);

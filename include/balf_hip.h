@@ -77,7 +77,8 @@ int balf_pack_weights(const float *const *tensors, int n_tensors, int precision,
                       void *packed_host, size_t packed_bytes);
 
 /* ---- detector forward ---------------------------------------------------------------------
- * x_nchw_dev : [B,3,Hp,Wp] fp32, Hp and Wp multiples of 64 (callers pad: test_utils.py:23-32)
+ * x_nchw_dev : [B,3,Hp,Wp] fp32, Hp and Wp multiples of 64 (callers pad: test_utils.py:23-32), Hp * Wp <= 2^25 pixels per
+ *              image (e.g. 5792 x 5792; BALF_ERR_SHAPE beyond: the kernels use 32-bit byte offsets inside an image)
  * logits_dev : [B,65,Hp/8,Wp/8] fp32 (post-BatchNorm, pre-softmax), may be NULL to skip
  * prob_dev   : [B,Hp,Wp] fp32 score map (softmax over 65, dustbin dropped, pixel-shuffled)
  * workspace  : balf_forward_workspace_bytes(B,Hp,Wp) bytes, 256-byte aligned */

@@ -61,6 +61,10 @@ def test_size_queries_and_argument_checks(lib):
     assert lib.balf_forward_workspace_bytes(8, 1088, 1920) < lib.balf_forward_workspace_bytes(16, 1088, 1920)
     assert lib.balf_forward_micro_batch(32, 1088, 1920) == 16 and lib.balf_forward_micro_batch(5, 1088, 1920) == 5
     assert lib.balf_forward_micro_batch(1, 100, 64) == 0
+    # one padded image may hold 2^25 pixels at most (32-bit byte offsets inside an image): refused before anything is launched
+    assert lib.balf_forward_workspace_bytes(1, 8192, 4096) > 0 and lib.balf_forward_workspace_bytes(1, 8192, 4160) == 0
+    fake = C.c_void_p(4096)
+    assert lib.balf_forward(fake, 1, fake, 1, 8192, 4160, None, fake, fake, 1 << 40, None) == -2
     assert lib.balf_nms_topk_workspace_bytes(2, 480, 640, 1000) >= 2 * 480 * 640 * 8
     assert lib.balf_packed_weights_bytes(0) >= 1280728 * 4
     # host-side validation happens before anything touches a device
