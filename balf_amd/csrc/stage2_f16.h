@@ -31,9 +31,7 @@
 // + 32 = 154.9 KB with RSHMAG.dense2 (32 KB) streamed from L2 into registers per group (asm loads, counted waits).
 #pragma once
 
-constexpr int kS2C = 64, kS2Cin = 32;
-constexpr int kS2KS = kS2C / 16;                                  // K-steps (of 16 channels) of a Linear with C inputs
-constexpr int kS2KI = kS2Cin / 16;
+constexpr int kS2C = 64, kS2Cin = 32;                             // a Linear with C inputs is 4 K-steps of 16 channels, conv0 2
 
 #ifndef BALF_S2_NW0
 #define BALF_S2_NW0 8

@@ -179,9 +179,15 @@ def test_se_channel_sums_add_both_results_of_their_row_swap():
     va = _audit_module()
     kernels = va.disassemble(_lib.LIB_PATH, r"stage1_kernel16ILi1ELb[01]")
     assert len(kernels) == 2, list(kernels)
+    # the stage-2 block kernel (stage2_f16.h) has the same reduction over twice the registers; its first build summed
+    # register 0 sixteen times (__builtin_bit_cast applied to a vector element reads element 0: DESIGN 4.3f) -- the built code
+    # then held TWO swaps instead of sixteen
+    k2 = va.disassemble(_lib.LIB_PATH, r"stage2_kernel16ILi1E")
+    assert len(k2) == 1, list(k2)
+    kernels.update(k2)
     for name, ins in kernels.items():
         swaps = [(i, ops) for i, (_, mn, ops) in enumerate(ins) if mn and mn.startswith("v_permlane16_swap")]
-        assert len(swaps) == 8, (name, len(swaps))              # one per register pair (r, r + 8) of the 16-channel sums
+        assert len(swaps) == (16 if "stage2" in name else 8), (name, len(swaps))   # one per register pair (r, r + 8) of a tile's sums
         for i, ops in swaps:
             a, b = (_regs(o.strip()) for o in ops.split(","))
             assert a and b and not (a & b), (name, ops)
