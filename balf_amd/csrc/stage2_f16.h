@@ -147,12 +147,15 @@ __device__ __forceinline__ void s2_linear_regs(f16v &acc, const HL (&a)[4], cons
     for (int s = 0; s < 4; ++s) acc = mfma32(a[s].hi, b[s].hi, acc);
 }
 
+#ifndef BALF_S2_GELU_CH
+#define BALF_S2_GELU_CH 8    // table reads in flight per chunk of the software pipeline (stage1_f16.h: gelu_lut_pipe)
+#endif
 template <int MODE>
 __device__ __forceinline__ void s2_gelu(f16v (&t)[2]) {
     if (BALF_ABLATE_GELU) return;
     float magic = 12582912.0f;                   // 1.5 * 2^23 (see s1_gelu)
     asm("" : "+v"(magic));
-    gelu_lut_pipe<BALF_S1_GELU_CH, s2_lut_n<MODE>()>(t, magic);
+    gelu_lut_pipe<BALF_S2_GELU_CH, s2_lut_n<MODE>()>(t, magic);
 }
 
 // ---- pair synchronisation through LDS counters (raw LDS addresses: these kernels have no static LDS) ----

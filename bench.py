@@ -440,6 +440,8 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-single-rank-collective", action="store_true",
                     help="at N = 1 skip the single-rank RCCL group (then the step has no collective)")
+    ap.add_argument("--allow-diagnostic-build", action="store_true",
+                    help="time a library built with a switch of csrc/diag.h (BALF_HIP_LIB=...); its metric field says INVALID")
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)   # launcher test on the CPU (gloo), see stub_main
     args = ap.parse_args()
 
@@ -494,6 +496,9 @@ def main():
     from balf_amd import _lib as _balf_lib
     build_flags = _balf_lib.lib().balf_build_flags().decode()
     if not build_flags.startswith("release"):
+        if not args.allow_diagnostic_build:
+            raise SystemExit(f"[bench] {_balf_lib.LIB_PATH} is a DIAGNOSTIC build ({build_flags}): it computes wrong results; "
+                             "refusing to measure it (--allow-diagnostic-build for a timing experiment: the line then says INVALID)")
         print(f"[bench] DIAGNOSTIC library build: {build_flags}", file=sys.stderr)
     h, w, k, b = args.height, args.width, args.topk, args.batch_per_gpu
     hp, wp, top, left = arch.padded_hw(h, w)
