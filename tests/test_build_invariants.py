@@ -230,3 +230,31 @@ def test_tail_kernel_pools_sixteen_distinct_values():
                 assert d is not None, (name, pat, i)
                 defs.add(d)
             assert len(defs) == 16, (name, pat, sorted(defs))
+
+
+def test_the_vmcnt_audit_itself_catches_what_it_is_for():
+    """The audit of the hand-counted waits (tools/vmcnt_audit.py) on synthetic loops: it accepts a correct schedule and names (a) a
+    wait whose count is larger than the number of younger vector-memory operations, (b) a compiler-style copy of the load's
+    destination in front of the wait (the round-2 race), (c) a load that no wait covers within an iteration."""
+    va = _audit_module()
+
+    def loop(body):
+        return [("L1", None, None)] + [(None, mn, ops) for mn, ops in body] + [(None, "s_cbranch_scc1", "L1")]
+    store = ("global_store_dwordx4", "v[100:101], v[40:43], off")
+    good = loop([("s_waitcnt", "vmcnt(2)"), ("v_add_f32_e32", "v9, v4, v5"),
+                 ("global_load_dwordx4", "v[4:7], v20, s[2:3]"), store, store])
+    problems, checked, margins = va.audit(good)
+    assert not problems and checked == 1 and margins == [(2, 2)], (problems, checked, margins)
+    # (a) the wait allows three operations in flight but only two are younger than the load: the load may still be one of them
+    bad_count = loop([("s_waitcnt", "vmcnt(3)"), ("v_add_f32_e32", "v9, v4, v5"),
+                      ("global_load_dwordx4", "v[4:7], v20, s[2:3]"), store, store])
+    assert va.audit(bad_count)[0], "a wait that does not cover its load went unnoticed"
+    # (b) the destination is copied in front of the wait
+    bad_copy = loop([("v_mov_b32_e32", "v30, v4"), ("s_waitcnt", "vmcnt(2)"), ("v_add_f32_e32", "v9, v30, v5"),
+                     ("global_load_dwordx4", "v[4:7], v20, s[2:3]"), store, store])
+    p = va.audit(bad_copy)[0]
+    assert p and "touches the destination" in p[0], p
+    # (c) no counted wait at all behind the load
+    no_wait = loop([("s_waitcnt", "vmcnt(2)"), ("global_load_dwordx4", "v[4:7], v20, s[2:3]"), store, store,
+                    ("global_load_dwordx4", "v[12:15], v21, s[2:3]"), ("s_waitcnt", "lgkmcnt(0)")])
+    assert va.audit(no_wait)[0]
