@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
 #include "stage1_f16.h"
 #include "stage2_f16.h"
 #include "stage_cs_f16.h"
+#include "stage3_tail_f16.h"
 
 // Stages 1-3 leave x1 + the hidden-layer channel sums and a tail kernel forms the next stage's input; stage 4 stores t and
 // r for the head kernel.
@@ -403,7 +404,7 @@ int ensure_kernel_attributes() {
     ok = ok && allow_lds(stage2_kernel16<0>, s2_lds_bytes<0>()) && allow_lds(stage2_kernel16<1>, s2_lds_bytes<1>()) &&
          allow_lds(stage2_kernel16<2>, s2_lds_bytes<2>());
     ok = ok && allow_lds(stage_cs_kernel16<128, 64, 0>, cs_launch_lds<128, 0>()) && allow_lds(stage_cs_kernel16<128, 64, 1>, cs_launch_lds<128, 1>()) &&
-         allow_lds(stage_cs_kernel16<128, 64, 2>, cs_launch_lds<128, 2>());
+         allow_lds(stage3_tail_kernel16, kT3LdsBytes);
     ok = ok && allow_lds(stage_cs_kernel16<256, 128, 0>, cs_launch_lds<256, 0>()) && allow_lds(stage_cs_kernel16<256, 128, 1>, cs_launch_lds<256, 1>());
     if (!ok) return BALF_ERR_LAUNCH;
     done |= 1ull << dev;
@@ -462,6 +463,11 @@ int run_tail_cs16(const float *blob, int s, const float *X, const float *R, cons
     const long groups = (long)B * (H / 8) * (W / 8);
     if constexpr (C == 64) {
         BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(stage2_kernel16<2>, dim3(s1_blocks(groups, s2_waves<2>() / 2)), dim3(s2_waves<2>() * 64), s2_lds_bytes<2>(), st, a));
+        BALF_LAUNCH_CHECK();
+        return BALF_OK;
+    } else if constexpr (C == 128) {
+        // persistent, every wave owns half a token group (stage3_tail_f16.h)
+        BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(stage3_tail_kernel16, dim3(s1_blocks(2 * groups, kT3Waves)), dim3(kT3Waves * 64), kT3LdsBytes, st, a));
         BALF_LAUNCH_CHECK();
         return BALF_OK;
     } else {

@@ -32,6 +32,8 @@ def slot_of(kernel: str):
     m = re.match(r"stage2_kernel16<(\d)", k)
     if m:
         return "stage2_pool" if m.group(1) == "2" else "stage2_%s_branch" % ("grid" if m.group(1) == "0" else "block")
+    if k.startswith("stage3_tail_kernel16"):
+        return "stage3_pool"
     m = re.match(r"stage_cs_kernel16<(\d+), \d+, (\d)>", k)
     if m:
         st = [32, 64, 128, 256].index(int(m.group(1))) + 1
