@@ -65,6 +65,15 @@ def test_size_queries_and_argument_checks(lib):
     assert lib.balf_forward_workspace_bytes(1, 8192, 4096) > 0 and lib.balf_forward_workspace_bytes(1, 8192, 4160) == 0
     fake = C.c_void_p(4096)
     assert lib.balf_forward(fake, 1, fake, 1, 8192, 4160, None, fake, fake, 1 << 40, None) == -2
+    # the stage view validates on the host before anything is launched: stage 1..4, the micro-batch that is resident, the workspace
+    ws_bytes = lib.balf_forward_workspace_bytes(2, 64, 64)
+    assert lib.balf_forward_stage_view_numel(2, 64, 64, 1) == 2 * 32 * 32 * 32 and lib.balf_forward_stage_view_numel(2, 64, 64, 4) == 2 * 8 * 8 * 256
+    assert lib.balf_forward_stage_view_numel(2, 64, 64, 0) == 0 and lib.balf_forward_stage_view_numel(2, 64, 64, 5) == 0
+    assert lib.balf_forward_stage_view(1, fake, ws_bytes, 2, 64, 64, 5, fake, None) == -1            # no such stage
+    assert lib.balf_forward_stage_view(7, fake, ws_bytes, 2, 64, 64, 1, fake, None) == -1            # no such precision
+    assert lib.balf_forward_stage_view(1, fake, ws_bytes - 1, 2, 64, 64, 1, fake, None) == -3        # workspace too small
+    assert lib.balf_forward_stage_view(1, fake, 1 << 40, 17, 1088, 1920, 1, fake, None) == -1        # 17 images: two micro-batches
+    assert lib.balf_forward_stage_view(1, fake, ws_bytes, 2, 60, 64, 1, fake, None) == -2
     assert lib.balf_nms_topk_workspace_bytes(2, 480, 640, 1000) >= 2 * 480 * 640 * 8
     assert lib.balf_packed_weights_bytes(0) >= 1280728 * 4
     # host-side validation happens before anything touches a device
