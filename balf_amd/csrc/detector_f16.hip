@@ -376,7 +376,7 @@ template <int C> constexpr bool stage_fused() { return C == 32 || C == 64 || cs_
 
 // ---- dynamic-LDS sizes of every kernel this file launches, and their one-time registration ----
 template <int C, int MODE> constexpr int cs_launch_lds() {
-    return MODE == 2 ? cs_tail_lds_bytes<C>() * cs_groups<C>() : cs_lds_bytes<C>() * cs_groups<C>() + cs_lut_bytes<MODE>();
+    return cs_lds_bytes<C>() * cs_groups<C>() + cs_lut_bytes<MODE>();
 }
 static_assert(s1_lds_bytes<0>() <= 160 * 1024 && s1_lds_bytes<1>() <= 160 * 1024 && s1_lds_bytes<2>() <= 160 * 1024, "stage-1 LDS image");
 static_assert(s2_lds_bytes<0>() <= 160 * 1024 && s2_lds_bytes<1>() <= 160 * 1024 && s2_lds_bytes<2>() <= 160 * 1024, "stage-2 LDS image");
@@ -455,30 +455,20 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
     return BALF_OK;
 }
 
-// Tail of stages 2-3 (stage_cs_kernel16<C, CIN, 2>): the stage input X, x1 (in R) and the SE scale -> the next stage's input.
-template <int C, int CIN>
-int run_tail_cs16(const float *blob, int s, const float *X, const float *R, const float *scale, int B, int H, int W, float *out,
-                  hipStream_t st) {
+// Tail of stages 2-3 (stage2_kernel16<2> / stage3_tail_kernel16, both persistent): the stage input X, x1 (in R) and the SE scale
+// -> the next stage's input.
+template <int C>
+int run_tail23(const float *blob, int s, const float *X, const float *R, const float *scale, int B, int H, int W, float *out,
+               hipStream_t st) {
+    static_assert(C == 64 || C == 128, "stage 4 has no tail kernel: its consumer is the head kernel");
     StageArgs a{blob, kLayout.st[s], X, nullptr, 0, 0, 0, 0, 0, B, H, W, nullptr, nullptr, const_cast<float *>(R), nullptr, scale, out};
     const long groups = (long)B * (H / 8) * (W / 8);
-    if constexpr (C == 64) {
+    if constexpr (C == 64)      // every wave PAIR walks its own list of groups (stage2_f16.h)
         BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(stage2_kernel16<2>, dim3(s1_blocks(groups, s2_waves<2>() / 2)), dim3(s2_waves<2>() * 64), s2_lds_bytes<2>(), st, a));
-        BALF_LAUNCH_CHECK();
-        return BALF_OK;
-    } else if constexpr (C == 128) {
-        // persistent, every wave owns half a token group (stage3_tail_f16.h)
+    else                        // every wave owns half a token group (stage3_tail_f16.h)
         BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(stage3_tail_kernel16, dim3(s1_blocks(2 * groups, kT3Waves)), dim3(kT3Waves * 64), kT3LdsBytes, st, a));
-        BALF_LAUNCH_CHECK();
-        return BALF_OK;
-    } else {
-        constexpr int G = cs_groups<C>();
-        if (groups % G != 0) return BALF_ERR_ARG;
-        auto k = stage_cs_kernel16<C, CIN, 2>;
-        constexpr int lds = cs_launch_lds<C, 2>();
-        BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(k, dim3((unsigned)(groups / G)), dim3(cs_waves<C>() * G * 64), lds, st, a));
-        BALF_LAUNCH_CHECK();
-        return BALF_OK;
-    }
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
 }
 
 // Stage-1 tail (stage1_kernel16<2>): x1 (in R), the image and the SE scale -> the next stage's input.
@@ -529,12 +519,12 @@ int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
         if ((rc = run_stage16<32, 3>(blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_tail16(blob, x, u8b, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
         if ((rc = run_stage16<64, 32>(blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_tail_cs16<64, 32>(blob, 1, X2, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
+        if ((rc = run_tail23<64>(blob, 1, X2, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
 #if BALF_DEBUG_STOP
         if (const char *e = getenv("BALF_DEBUG_STOP_STAGE"); e && atoi(e) == 2) return BALF_OK;
 #endif
         if ((rc = run_stage16<128, 64>(blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_tail_cs16<128, 64>(blob, 2, X3, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
+        if ((rc = run_tail23<128>(blob, 2, X3, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
         if ((rc = run_stage16<256, 128>(blob, 3, X4, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         HeadArgs ha{blob, kLayout.st[3], kLayout.head_w, kLayout.head_b, kLayout.head_alpha, kLayout.head_beta,
                     T, R, scale, nb, h8, w8,

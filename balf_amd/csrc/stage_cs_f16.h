@@ -27,16 +27,10 @@ template <int C> constexpr int cs_bt_bytes() {                                  
     return bt > bu ? bt : bu;
 }
 template <int C> constexpr bool cs_mix_in_lds() { return C >= 256; }
-// Fused tail (as in stage 1, stage1_f16.h): the block kernel stores x1 and the channel sums of the RCAB's hidden layer;
-// MODE 2 of the kernel below recomputes x0 and the RCAB branch from x1, scales, pools and writes the next stage's input.
-// Measured per stage (ms per 8 images at 1088x1920, block + pool -> block + tail): C = 64 1.98 -> 1.75; C = 128 1.32 -> 1.28
-// (there the tail streams conv0 + conv1 + conv2 -- 164 KB per token group -- from L2, which is what bounds it: 0.23 ms
-// with the weight tiles served from L1 in an ablation build, 0.35 ms as it is, against 0.24 ms of the pool kernel).
-// Not at C = 256: there the consumer is the head kernel.
+// Fused tail (as in stages 1-2): at C = 128 the block kernel stores x1 and the channel sums of the RCAB's hidden layer, and a tail
+// kernel (stage3_tail_f16.h; until round 4 MODE 2 of the kernel below) recomputes x0 and the RCAB branch from x1, scales, pools and
+// writes the next stage's input.  Not at C = 256: there the consumer is the head kernel.
 template <int C> constexpr bool cs_fused() { return C <= 128; }
-template <int C> constexpr int cs_tail_lds_bytes() {      // tail: B fragments, statistics, the stage input (no token tiles)
-    return cs_bx_bytes<C>() + cs_waves<C>() * 4 * 16 * 8 + (C / 64) * 4 * 2048;
-}
 template <int C> constexpr int cs_lds_bytes() {
     return cs_bx_bytes<C>() + cs_bt_bytes<C>() + (cs_mix_in_lds<C>() ? 8 * 2048 : 0) + cs_waves<C>() * 4 * 16 * 8;
 }
@@ -201,57 +195,13 @@ __device__ __forceinline__ void cs_linear(f4 (&acc)[2][4], const CsW &first, con
     }
 }
 
-// All weight fragments of a Linear of this wave at once (the tail kernels: few live tensors, so a whole Linear's tiles
-// -- 64 registers at C = 128 -- can be requested a Linear ahead and no L2 round trip is left inside the K loop).
-template <int KSN>
-struct CsWAll {
-    HL a[KSN][2];
-};
-template <int KSN>
-__device__ __forceinline__ void cs_wload_all(CsWAll<KSN> &w, const CsBlob &bl, unsigned wbase) {
-#pragma unroll
-    for (int s = 0; s < KSN; ++s)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const unsigned o = wbase + (unsigned)((t * KSN + s) * 2048);
-            w.a[s][t].hi = bl.frag(o);
-            w.a[s][t].lo = bl.frag(o + 1024);
-        }
-}
-template <int KSN, typename BS>
-__device__ __forceinline__ void cs_linear_all(f4 (&acc)[2][4], const CsWAll<KSN> &w, BS bsrc, int lane) {
-#pragma unroll
-    for (int s = 0; s < KSN; ++s) {
-        const h8 *bk = bsrc(s);
-        HL b[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            b[p].hi = bk[(p * 2 + 0) * 64 + lane];
-            b[p].lo = bk[(p * 2 + 1) * 64 + lane];
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) if (!BALF_DROP_WLO) acc[t][p] = mfma16(w.a[s][t].lo, b[p].hi, acc[t][p]);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc[t][p] = mfma16(w.a[s][t].hi, b[p].lo, acc[t][p]);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc[t][p] = mfma16(w.a[s][t].hi, b[p].hi, acc[t][p]);
-    }
-}
-
 #ifndef BALF_CS_G
 #define BALF_CS_G 1          // token groups per workgroup at C <= 128 (2: the paired waves of the two groups request the same weight lines in step)
 #endif
 template <int C> constexpr int cs_groups() { return C <= 128 ? BALF_CS_G : 1; }
-// waves per SIMD the tail kernels are compiled for: 3 at C = 64 (156 registers), 2 at C = 128 (two Linears' tiles in flight)
-template <int C> constexpr int cs_tail_wps() { return C <= 64 ? 3 : 2; }
 template <int C, int CIN, int MODE>
-__global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs_tail_wps<C>() : 2) void stage_cs_kernel16(StageArgs A) {
+__global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, 2) void stage_cs_kernel16(StageArgs A) {
+    static_assert(MODE == 0 || MODE == 1, "grid branch / block branch");
     constexpr int NW = cs_waves<C>(), KS = C / 32, KI = CIN / 32, NT = C / 16, P = 4, G = cs_groups<C>();
     constexpr int STAMP_KID = (C == 64 ? 1 : C == 128 ? 2 : 3) * 2 + (MODE & 1); (void)STAMP_KID;   // (diagnostic build only)
     STAMPV_DECL;
@@ -260,22 +210,19 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
     // (G = 2) two token groups per workgroup, each with its own LDS image and its own waves; they share the barriers only
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = (G == 1) ? 0 : wave_all / NW;
-    unsigned char *smem_raw = smem_all + (MODE == 2 ? grp * cs_tail_lds_bytes<C>() : cs_lut_bytes<MODE>() + grp * cs_lds_bytes<C>());
+    unsigned char *smem_raw = smem_all + cs_lut_bytes<MODE>() + grp * cs_lds_bytes<C>();
     h8 *bx = reinterpret_cast<h8 *>(smem_raw);                                            // shared B fragments
     unsigned char *btr = smem_raw + cs_bx_bytes<C>();                                      // token tiles, later u'
     h8 *bu = reinterpret_cast<h8 *>(btr);
     const unsigned char *wmix_l = btr + cs_bt_bytes<C>();                                  // (C = 256) re-ordered Wmix
-    float *stats = reinterpret_cast<float *>(smem_raw + cs_bx_bytes<C>() +                 // [NW][4][16] (sum, sumsq)
-                                             (MODE == 2 ? 0 : cs_bt_bytes<C>() + (cs_mix_in_lds<C>() ? 8 * 2048 : 0)));
-    // the stage input's fragments: in bx (conv0 is the first Linear), or (tail) in a region of their own behind the statistics
-    h8 *bxin = (MODE == 2) ? reinterpret_cast<h8 *>(smem_raw + cs_bx_bytes<C>() + cs_waves<C>() * 4 * 16 * 8) : bx;
+    float *stats = reinterpret_cast<float *>(smem_raw + cs_bx_bytes<C>() + cs_bt_bytes<C>() +   // [NW][4][16] (sum, sumsq)
+                                             (cs_mix_in_lds<C>() ? 8 * 2048 : 0));
     const int lane = threadIdx.x & 63, q = lane >> 4, li = lane & 15;
     const int wave = wave_all - grp * NW;
     unsigned char *bT = btr + wave * kS1BtBytes;
     const float *blob = A.blob;
     const StageOff &S = A.off;
     const BranchOff &Br = S.br[MODE == 0 ? 0 : 1];
-    constexpr bool TAIL = MODE == 2;
     constexpr int kGeluChunk = BALF_CS_GELU_CHUNK; (void)kGeluChunk;
     const char *bb = reinterpret_cast<const char *>(blob);
     const CsBlob bl{__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(blob), 0, 0x7fffffff, 0x27000), (unsigned)lane * 16u};
@@ -298,18 +245,6 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
     const long pix0 = ((long)n * H + y) * W + xl0;
 
     auto barrier = [&]() { lds_barrier(); };                 // lgkmcnt(0) + s_barrier: never drains loads or stores
-    // (tail) x1 as the block kernel left it and this image's SE scale, requested first
-    f4 x1t[TAIL ? 2 : 1][TAIL ? 4 : 1], sct[2];
-    if constexpr (TAIL) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            sct[nt] = *reinterpret_cast<const f4 *>(A.scale + (long)n * C + c0 + 16 * nt + 4 * q);
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                x1t[nt][p] = *reinterpret_cast<const f4 *>(A.R + (pix0 + p * pstep) * C + c0 + 16 * nt + 4 * q);
-        }
-    }
-
     // ---- stage input -> shared B fragments (KI x 4 fragments, two per wave); (C = 256) the re-ordered mixing matrix ----
     {
         static_assert(KI * 4 == 2 * NW, "two input fragments per wave");           // holds for C = 64, 128, 256
@@ -340,12 +275,12 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             const int fi = 2 * wave + f;
-            bxin[(fi * 2 + 0) * 64 + lane] = xin[f].hi;
-            bxin[(fi * 2 + 1) * 64 + lane] = xin[f].lo;
+            bx[(fi * 2 + 0) * 64 + lane] = xin[f].hi;
+            bx[(fi * 2 + 1) * 64 + lane] = xin[f].lo;
         }
     }
     STAMPV(19);  // (diagnostic) input fragments arrived and written to LDS
-    if constexpr (!TAIL) barrier();                            // (tail: conv0 runs last, behind the barriers of the RCAB branch)
+    barrier();
     STAMPV(1);   // input staged
 
     struct Bias { f4 b[2]; };
@@ -437,7 +372,7 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
     const unsigned w_c0 = wptr(S.conv0_w, 0, KI, 0), w_q1 = wptr(S.q1_w, (MODE == 0 ? 0 : 1) * NT, KS, 0);
     const unsigned w_d1a = wptr(Br.d1_w, 0, KS, 0), w_d1b = wptr(Br.d1_w, NT, KS, 0), w_d2 = wptr(Br.d2_w, 0, KS, 0);
     f4 x0[2][4];
-    if constexpr (!TAIL) {
+    {
         CsW w;
         cs_wload<(KI == 1 ? 1 : 2)>(w, bl, w_c0, KI, 0);
         bias_fill(x0, bias_load(S.conv0_b));
@@ -445,62 +380,6 @@ __global__ __launch_bounds__(cs_waves<C>() * cs_groups<C>() * 64, MODE == 2 ? cs
     }
     STAMPV(2);   // conv0
     CsW wn;                                                    // the NEXT Linear's first fragments
-    if constexpr (TAIL) {
-        // ---- the stage's tail: x_next = maxpool2x2(x1 + x0 + s * conv2(lrelu(conv1(LN(x1))))) in fragment format ----
-        static_assert(KS <= 4, "the tail keeps whole Linears in registers");
-        const unsigned w_r1 = wptr(S.r1_w, 0, KS, 0), w_r2 = wptr(S.r2_w, 0, KS, 0);
-        CsWAll<KS> wa, wb;
-        CsWAll<KI> wc;
-        cs_wload_all(wa, bl, w_r1);
-        Bias bn = bias_load(S.r1_b);
-        ln_publish(x1t);
-        cs_wload_all(wb, bl, w_r2);                            // in flight through conv1 and the exchange of its output
-        f4 m1[2][4];
-        bias_fill(m1, bn);
-        cs_linear_all(m1, wa, from_bx, lane);
-        cs_wload_all(wc, bl, w_c0);
-        bn = bias_load(S.r2_b);
-        const Bias bc = bias_load(S.conv0_b);
-        lrelu(m1);
-        barrier();                                             // everyone is done with conv1's B operand
-        publish(bx, m1);
-        barrier();
-        f4 t[2][4];
-        bias_fill(t, bn);
-        cs_linear_all(t, wb, from_bx, lane);
-        // x0 = relu(conv0(X)) last: it is only needed for the sum below (32 registers less through the RCAB branch)
-        bias_fill(x0, bc);
-        cs_linear_all(x0, wc, [&](int ks) { return bxin + ks * (4 * 2 * 64); }, lane);
-        relu(x0);
-        // v = r + s t with r = x1 + x0 (the order of operations of pool_kernel16), max over the 2x2 window: the lane's
-        // tokens 2 pp, 2 pp + 1 are horizontal neighbours, the rows 2 j, 2 j + 1 sit in lanes li, li ^ 2
-        f4 mx[2][2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v0 = fmaf(t[nt][2 * pp][r], sct[nt][r], x1t[nt][2 * pp][r] + x0[nt][2 * pp][r]);
-                    const float v1 = fmaf(t[nt][2 * pp + 1][r], sct[nt][r], x1t[nt][2 * pp + 1][r] + x0[nt][2 * pp + 1][r]);
-                    const float m = __builtin_fmaxf(v0, v1);
-                    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                        0, __builtin_bit_cast(int, m), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, false));
-                    mx[nt][pp][r] = __builtin_fmaxf(m, o);
-                }
-        // both lanes of a row pair hold the same two pooled pixels: lane li stores pooled column 2 (li & 1) + ((li >> 1) & 1)
-        const int sel = (li >> 1) & 1;
-        const unsigned selm = 0u - (unsigned)sel;              // all ones in the lanes that take the second column (v_bfi, not v_cndmask)
-        f4 o0, o1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            o0[r] = lane_select(selm, mx[0][1][r], mx[0][0][r]);
-            o1[r] = lane_select(selm, mx[1][1][r], mx[1][0][r]);
-        }
-        const long opix = ((long)n * (H / 2) + (y >> 1)) * (W / 2) + (xl0 >> 1) + sel;
-        store_frag_px(A.out, opix, C, wave, q, split8(o0, o1));
-        return;
-    }
     cs_wload(wn, bl, w_q1, KS, 0);
     Bias bn = bias_load(S.q1_b + MODE * C);
     relu(x0);

@@ -114,7 +114,6 @@ def main():
     with torch.no_grad():
         hid = F.leaky_relu(O._lin(sd, r + ".conv1", O._ln(sd, r + ".norm", taps["down2.x1"])), 0.2)
     part = ws[off["partial"]:off["partial"] + b * fh * fw * 2 * 64 * 4].view(torch.float32).view(b, fh, fw, 2, 64)
-    ref_part = torch.stack([hid[:, 4 * wv:, :, :].reshape(b, fh, 8, fw, 8, 64)[:, :, 0:4].sum(dim=(2, 4)) for wv in range(1)], 3)
     hid6 = hid.reshape(b, fh, 8, fw, 8, 64)
     ref_part = torch.stack([hid6[:, :, 0:4].sum(dim=(2, 4)), hid6[:, :, 4:8].sum(dim=(2, 4))], dim=3)     # [b, fh, fw, half, c]
     e = rel("partial", part, ref_part)
