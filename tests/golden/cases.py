@@ -13,6 +13,16 @@ FORWARD_SMALL = {
     "b1_256x320": (1, 256, 320, 13),
 }
 TAP_CASE = "b2_64x64"
+# per-stage outputs of the two larger cases, sampled (stage_taps.npz): every 3rd row / 5th column of the stage's NCHW output --
+# all in-cell offsets of the grid branch and all positions of the 8x8 blocks come up -- plus the float64 sum of every channel
+# (every pixel enters)
+TAP_SAMPLED = ("b1_128x192", "b1_256x320")
+
+
+def stage_sample(v):
+    """NCHW stage output -> (strided sample, per-channel float64 sums)"""
+    v = np.asarray(v)
+    return v[:, :, ::3, ::5].copy(), v.astype(np.float64).sum(axis=(0, 2, 3))
 
 # name -> (h, w, K, synthetic image index)  un-padded image sizes, run through pad/crop
 FORWARD_CFG = {

@@ -9,6 +9,8 @@ and never travels to the GPU box):
 What is recorded is data only -- inputs are regenerated from seeds, outputs are arrays:
   forward_small.npz   logits/prob (+ per-stage outputs) of the reference model with the
                       seeded synthetic weights of balf_amd.utils.synth on small inputs
+  stage_taps.npz      (round 4) per-stage outputs of the reference's down1..down4 (forward hooks) on the two larger small
+                      cases, sampled (cases.stage_sample) + per-channel float64 sums
   forward_cfg.npz     strided prob samples + reference top-K index lists at 512x640
   nms_topk.npz        remove_borders/apply_nms/find_index_higher_scores results on synthetic
                       score maps (random, tie-heavy, all-zero, sparse, even window sizes)
@@ -149,11 +151,12 @@ def main():
     # ---------------- forward, small ----------------
     m, cfg = ref_model(cases.WEIGHT_SEED)
     fw = {}
+    taps = {}
     for name, (b, h, w, seed) in cases.FORWARD_SMALL.items():
         x = cases.forward_input(b, h, w, seed)
         stage_out = {}
         hooks = []
-        if name == cases.TAP_CASE:
+        if name == cases.TAP_CASE or name in cases.TAP_SAMPLED:
             for s in ("down1", "down2", "down3", "down4"):
                 hooks.append(getattr(m, s).register_forward_hook(
                     lambda mod, i, o, s=s: stage_out.__setitem__(s, o.detach().numpy().copy())))
@@ -164,8 +167,12 @@ def main():
         fw[name + ".logits"] = o["logits"].numpy()
         fw[name + ".prob"] = o["prob"].numpy()
         for s, v in stage_out.items():
-            fw[f"{name}.{s}"] = v          # NCHW, as the reference's Down returns it
+            if name == cases.TAP_CASE:
+                fw[f"{name}.{s}"] = v      # NCHW, as the reference's Down returns it
+            else:                          # (round 4) the larger cases: sampled, in a file of their own
+                taps[f"{name}.{s}.sample"], taps[f"{name}.{s}.chansum"] = cases.stage_sample(v)
     np.savez_compressed(os.path.join(HERE, "forward_small.npz"), **fw)
+    np.savez_compressed(os.path.join(HERE, "stage_taps.npz"), **taps)
 
     # ---------------- forward at a config size (strided samples + detections) ----------------
     # The score map is taken from inside the reference's own caller: extract_detections runs pad -> model -> crop ->

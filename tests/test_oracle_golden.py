@@ -59,6 +59,23 @@ def test_stage_outputs(sd, fsmall):
             assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("name", cases.TAP_SAMPLED)
+def test_stage_outputs_sampled(sd, name):
+    """The oracle's stages against the reference's own down1..down4 outputs at 128x192 and 256x320 (stage_taps.npz: strided
+    samples + per-channel sums; recorded through forward hooks on the reference's modules)."""
+    f = np.load(os.path.join(G, "stage_taps.npz"))
+    b, h, w, seed = cases.FORWARD_SMALL[name]
+    x = cases.forward_input(b, h, w, seed).permute(0, 2, 3, 1)
+    with torch.no_grad():
+        for i in range(4):
+            x = O.stage_forward(sd, f"down{i + 1}", x, last=(i == 3))
+            got, gsum = cases.stage_sample(x.permute(0, 3, 1, 2).numpy())
+            ref, rsum = f[f"{name}.down{i + 1}.sample"], f[f"{name}.down{i + 1}.chansum"]
+            assert got.shape == ref.shape
+            assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+            assert np.abs(gsum - rsum).max() < 1e-5 * max(1.0, np.abs(rsum).max()) * x.shape[1] * x.shape[2] ** 0.5
+
+
 def test_forward_cfg_vga(sd):
     f = np.load(os.path.join(G, "forward_cfg.npz"))
     h, w, k, img_index = cases.FORWARD_CFG["vga"]

@@ -58,6 +58,31 @@ def test_stage_outputs_vs_reference_golden(precision):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16"])
+@pytest.mark.parametrize("name", cases.TAP_SAMPLED)
+def test_stage_outputs_vs_reference_samples(precision, name):
+    """The same against the reference at 128x192 and 256x320 (stage_taps.npz: what forward hooks on the reference's down1..down4
+    returned, sampled every 3rd row / 5th column + per-channel float64 sums over every pixel): non-square grids (fh / fw = 16 / 24
+    and 32 / 40 at stage 1, 8 / 12 and 16 / 20 at stage 2), pinned on the reference itself rather than on the oracle."""
+    f = np.load(os.path.join(G, "stage_taps.npz"))
+    b, h, w, seed = cases.FORWARD_SMALL[name]
+    sd = synth.synthetic_state_dict(cases.WEIGHT_SEED)
+    m = _model(precision)
+    with torch.inference_mode():
+        m(cases.forward_input(b, h, w, seed).to("cuda:0"))
+        views = [v.cpu().numpy() for v in m.stage_view(b, h, w)]
+    for s in range(4):
+        full = np.moveaxis(views[s], 3, 1) if s < 3 else _down4(sd, views[3])
+        got, gsum = cases.stage_sample(full)
+        ref, rsum = f[f"{name}.down{s + 1}.sample"], f[f"{name}.down{s + 1}.chansum"]
+        assert got.shape == ref.shape, (s, got.shape, ref.shape)
+        rel = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+        npx = full.shape[2] * full.shape[3]
+        srel = float(np.abs(gsum - rsum).max() / (max(1.0, np.abs(ref).max()) * npx))      # mean error per pixel, relative
+        print(f"{precision} {name} down{s + 1}: sample rel {rel:.2e}, channel-sum rel per pixel {srel:.2e}")
+        assert rel < GATE[precision] and srel < GATE[precision], (precision, name, s + 1, rel, srel)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
 @pytest.mark.parametrize("b,h,w,seed", [(1, 256, 320, 5), (3, 128, 192, 6)])
 def test_stage_outputs_vs_oracle(precision, b, h, w, seed):
     """fh = 32 / fw = 40 and 16 / 24 in the stage-1 grid branch (the golden above has 8 x 8), batch 3 with an odd image count."""
