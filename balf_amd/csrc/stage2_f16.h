@@ -299,8 +299,28 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
     int item = xcd * npx + px;                                   // wave-uniform; the same for both waves of a pair
     Pos nxt = decompose(item);
     HL nx[2] = {};
-    if (!TAIL && item < total) {
+    // (tail) x1 of the next half group as the block kernel left it -- register order: per wave half 8 KB = [tile][register quad]
+    // [lane] x 16 B --, prefetched like the input fragments
+    f4 nx1[TAIL ? 2 : 1][TAIL ? 4 : 1] = {};
+    auto issue_x1 = [&](int it) {
+        if constexpr (TAIL) {
+            const char *rp = uniform_ptr(reinterpret_cast<const char *>(A.R) + ((long)it * 2 + w) * (32 * C * 4));
+            const unsigned lo16 = (unsigned)lane * 16u;
+            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %8, %9\n\tglobal_load_dwordx4 %1, %8, %9 offset:1024\n\t"
+                         "global_load_dwordx4 %2, %8, %9 offset:2048\n\tglobal_load_dwordx4 %3, %8, %9 offset:3072\n\t"
+                         "global_load_dwordx4 %4, %8, %10\n\tglobal_load_dwordx4 %5, %8, %10 offset:1024\n\t"
+                         "global_load_dwordx4 %6, %8, %10 offset:2048\n\tglobal_load_dwordx4 %7, %8, %10 offset:3072"
+                         : "+v"(nx1[0][0]), "+v"(nx1[0][1]), "+v"(nx1[0][2]), "+v"(nx1[0][3]), "+v"(nx1[1][0]), "+v"(nx1[1][1]),
+                           "+v"(nx1[1][2]), "+v"(nx1[1][3])
+                         : "v"(lo16), "s"(rp), "s"(rp + 4096) : "memory");
+        }
+    };
+    if (item < total) {
         issue_in(geo(nxt), nx);
+        issue_x1(item);
+        if constexpr (TAIL)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx1[0][0]), "+v"(nx1[0][1]), "+v"(nx1[0][2]), "+v"(nx1[0][3]), "+v"(nx1[1][0]),
+                         "+v"(nx1[1][1]), "+v"(nx1[1][2]), "+v"(nx1[1][3])::"memory");
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx[0].hi), "+v"(nx[0].lo), "+v"(nx[1].hi), "+v"(nx[1].lo)::"memory");
     }
     unsigned char *bT = smem_raw + M::tiles + (TAIL ? 0 : pair * kS1BtBytes);
@@ -315,22 +335,50 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
 
         if constexpr (TAIL) {
             // ---- the stage's tail: x_next = maxpool2x2(x1 + x0 + s * conv2(lrelu(conv1(LN(x1))))) in 16x16 fragment format ----
-            // x1 as the block kernel left it (register order: per wave half 8 KB = [tile][register quad][lane] x 16 B)
-            f16v x1t[2];
-            const float *rp = A.R + ((long)item * 2 + w) * (32 * C);
+            // x1 and the stage input's fragments were requested a group ago (younger: the previous group's two stores)
+            asm volatile(BALF_S2_WAIT(2) : "+v"(nx1[0][0]), "+v"(nx1[0][1]), "+v"(nx1[0][2]), "+v"(nx1[0][3]), "+v"(nx1[1][0]),
+                         "+v"(nx1[1][1]), "+v"(nx1[1][2]), "+v"(nx1[1][3]), "+v"(nx[0].hi), "+v"(nx[0].lo), "+v"(nx[1].hi),
+                         "+v"(nx[1].lo)::"memory");
+            // x0 = relu(conv0(X)) first, then LN(x1), then r = x1 + x0 IN x0's registers: from there on x1 and the input
+            // fragments are dead and the next group's can be requested into the same registers (no copies), with conv1, conv2
+            // and the pooling in front of them to cover the round trip
+            f16v x0[2];
+            s2_bias(x0, par + kS2pConv0B, h);
+            s2_linear<2>(x0, wl + M::conv0, nx);
+            relu32(x0);
+            HL b[4];
+            {
+                float s = nx1[0][0][0], ss = nx1[0][0][0] * nx1[0][0][0];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                        for (int r = (rt == 0 && gq == 0 ? 1 : 0); r < 4; ++r) { s += nx1[rt][gq][r]; ss = fmaf(nx1[rt][gq][r], nx1[rt][gq][r], ss); }
+                half_allreduce2(s, ss);
+                const float mean = s * (1.0f / C);
+                const float var = fmaf(ss, 1.0f / C, -mean * mean);
+                const float rstd = __builtin_amdgcn_rsqf(max0(var) + kLnEps), shift = -mean * rstd;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {                // K-step ks = register quads 2 (ks & 1), + 1 of tile ks >> 1
+                    f4 y0, y1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        y0[r] = fmaf(nx1[ks >> 1][2 * (ks & 1)][r], rstd, shift);
+                        y1[r] = fmaf(nx1[ks >> 1][2 * (ks & 1) + 1][r], rstd, shift);
+                    }
+                    b[ks] = split8<BALF_S1_SPLIT_MIX>(y0, y1);
+                }
+            }
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const f4 v = *reinterpret_cast<const f4 *>(rp + ((rt * 4 + gq) * 64 + lane) * 4);
+                for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x1t[rt][4 * gq + r] = v[r];
-                }
-            HL xin[2];
-            xin[0] = load_frag32(A.X, pix, kS2Cin, 0, h);
-            xin[1] = load_frag32(A.X, pix, kS2Cin, 1, h);
-            HL b[4];
-            s2_ln_split(x1t, b);
+                    for (int r = 0; r < 4; ++r) x0[rt][4 * gq + r] += nx1[rt][gq][r];           // r = x1 + x0
+            __builtin_amdgcn_sched_barrier(0);                   // everything that reads nx1 / nx has been issued
+            issue_in(geo(nxt), nx);
+            issue_x1(more ? item + stride : item);
             f16v m1[2];
             s2_bias(m1, par + kS2pR1B, h);
             s2_linear<4>(m1, wl + M::q1, b);
@@ -339,11 +387,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
             f16v t[2];
             s2_bias(t, par + kS2pR2B, h);
             s2_linear<4>(t, wl + M::d1, b);
-            f16v x0[2];
-            s2_bias(x0, par + kS2pConv0B, h);
-            s2_linear<2>(x0, wl + M::conv0, xin);
-            relu32(x0);
-            // v = r + s t with r = x1 + x0; max over the 2x2 window: tx partner = lane ^ 1, ty partner = lane ^ 8 (same 16-lane row)
+            // v = r + s t; max over the 2x2 window: tx partner = lane ^ 1, ty partner = lane ^ 8 (same 16-lane row)
             f16v mx[2];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -353,7 +397,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 4 * gq + r;
-                        const float v = fmaf(t[rt][i], sc[r], x1t[rt][i] + x0[rt][i]);
+                        const float v = fmaf(t[rt][i], sc[r], x0[rt][i]);
                         const int vi = __builtin_bit_cast(int, v);
                         const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
                         const float m = __builtin_fmaxf(v, o1);

@@ -95,6 +95,11 @@ def test_hand_counted_vmcnt_waits_cover_their_loads():
         assert checked == (4 if grid else 44), (name, checked)
         assert all(young >= n for n, young in margins), margins
         assert {n for n, _ in margins} == ({8} if grid else {0, 8, 12}), margins
+    # the stage-2 tail prefetches x1 (8 loads) and the input fragments (4) a group ahead; the compiler's own 8 loads of the
+    # squeeze-excite scale follow them in the queue, and its counted waits for those cover the prefetch as well
+    (name, ins), = va.disassemble(_lib.LIB_PATH, r"stage2_kernel16ILi2E").items()
+    problems, checked, margins = va.audit(ins)
+    assert not problems and checked == 20 and all(young >= n for n, young in margins), (name, problems, checked, margins)
 
 
 def test_table_gelu_kernels_have_no_static_lds(tmp_path):
