@@ -177,7 +177,7 @@ __device__ __forceinline__ void s2_poll(unsigned addr, unsigned target) {
 #define BALF_S2_WAIT(n) "s_waitcnt vmcnt(" #n ")"
 #endif
 
-// Vector-memory discipline (grid and block kernels), as in stage 1: vmcnt counts loads and stores together in issue order
+// Vector-memory discipline, as in stage 1: vmcnt counts loads and stores together in issue order
 // and hipcc drains it at the loop's back edge as soon as a load of its own is pending, so every LOAD of the loop is inline asm
 // with a hand-counted wait, the compiler sees only stores and never waits (tools/vmcnt_audit.py checks the built code).
 //   grid:  top of group i: wait for the input fragments of group i (younger: the 8 u' stores of group i-1 -> vmcnt(8));
@@ -185,6 +185,9 @@ __device__ __forceinline__ void s2_poll(unsigned addr, unsigned target) {
 //   block: the input fragments of group i+1 are requested late in group i and are covered by that group's last wait;
 //          RSHMAG.dense2's weights stream in four chunks of 8 loads through two register sets, the u' rows (8 loads) are
 //          requested in front of the first; see the waits in the loop body, each annotated with what is younger.
+//   tail:  x1 (8 loads) and the input fragments (4) of group i+1 are requested once group i has consumed its own (after
+//          r = x1 + x0); top of a group: vmcnt(2) (younger: the previous group's two stores).  The compiler's own loads of
+//          the squeeze-excite scale follow the prefetch in the queue; its counted waits for them cover the prefetch too.
 template <int MODE>
 __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(StageArgs A) {
     constexpr int C = kS2C, NW = s2_waves<MODE>(), NTHR = NW * 64, NP = NW / 2;
