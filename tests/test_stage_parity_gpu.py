@@ -103,6 +103,28 @@ def test_stage_outputs_vs_oracle(precision, b, h, w, seed):
             assert rel < GATE[precision], (precision, s + 1, rel)
 
 
+@pytest.mark.parametrize("b,h,w", [(1, 64, 128), (2, 128, 64), (1, 192, 192), (1, 64, 448), (1, 320, 64), (5, 64, 64), (2, 256, 128)])
+def test_stage_outputs_shape_sweep(b, h, w):
+    """Thin, tall, wide and tiny frames (fh or fw = 1 at stage 4, 2 at stage 3; 5 images of 16 token groups each: fewer groups
+    than the persistent kernels have wave pairs), split-f16 path against the oracle, stage by stage."""
+    sd = synth.synthetic_state_dict(cases.WEIGHT_SEED)
+    x = cases.forward_input(b, h, w, 100 + h + w)
+    m = _model("fp16")
+    with torch.inference_mode():
+        out = m(x.to("cuda:0"))
+        views = [v.cpu().numpy() for v in m.stage_view(b, h, w)]
+    t = x.permute(0, 2, 3, 1)
+    with torch.no_grad():
+        for s in range(4):
+            t = O.stage_forward(sd, f"down{s + 1}", t, last=(s == 3))
+            ref = t.numpy()
+            got = views[s] if s < 3 else np.moveaxis(_down4(sd, views[3]), 1, 3)
+            rel = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+            assert rel < GATE["fp16"], (b, h, w, s + 1, rel)
+        ref_prob = O.detector_forward(sd, x)["prob"].numpy()
+    assert np.abs(out["prob"].cpu().numpy() - ref_prob).max() < 2e-5
+
+
 def test_stage_view_rejects_what_is_not_resident():
     from balf_amd._lib import BalfHipError
     m = _model("fp16")
