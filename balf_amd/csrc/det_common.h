@@ -288,7 +288,6 @@ struct StageArgs {
     float *partial;       // [B, wgs_per_image, C] channel sums of t (stage 1, fused tail: of the RCAB's hidden layer)
     const float *scale;   // stage-1 tail kernel only: [B, C] squeeze-excite scale
     float *out;           // stage-1 tail kernel only: next stage's input, fragment format [B, H/2, W/2, C]
-    float *scratch;       // wave-team kernels (stage34_f16.h) only: register stash, 2 x 16 KiB per wave of the grid
 };
 
 struct InputU8 {           // optional raw-image input of the forward (ch = 0: none)

@@ -368,7 +368,6 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
 #include "stage1_f16.h"
 #include "stage2_f16.h"
 #include "stage_cs_f16.h"
-#include "stage34_f16.h"
 #include "stage3_tail_f16.h"
 
 // Stages 1-3 leave x1 + the hidden-layer channel sums and a tail kernel forms the next stage's input; stage 4 stores t and
@@ -407,8 +406,6 @@ int ensure_kernel_attributes() {
     ok = ok && allow_lds(stage_cs_kernel16<128, 64, 0>, cs_launch_lds<128, 0>()) && allow_lds(stage_cs_kernel16<128, 64, 1>, cs_launch_lds<128, 1>()) &&
          allow_lds(stage3_tail_kernel16, kT3LdsBytes);
     ok = ok && allow_lds(stage_cs_kernel16<256, 128, 0>, cs_launch_lds<256, 0>()) && allow_lds(stage_cs_kernel16<256, 128, 1>, cs_launch_lds<256, 1>());
-    ok = ok && allow_lds(stage_tm_kernel16<128, 64, 0>, tm_lds_bytes<128>()) && allow_lds(stage_tm_kernel16<128, 64, 1>, tm_lds_bytes<128>()) &&
-         allow_lds(stage_tm_kernel16<256, 128, 0>, tm_lds_bytes<256>()) && allow_lds(stage_tm_kernel16<256, 128, 1>, tm_lds_bytes<256>());
     if (!ok) return BALF_ERR_LAUNCH;
     done |= 1ull << dev;
     return BALF_OK;
@@ -438,12 +435,6 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
         auto g1 = u8.ch ? stage1_kernel16<1, true> : stage1_kernel16<1, false>;
         BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(g0, dim3(s1_blocks(groups, s1_waves<0>())), dim3(s1_waves<0>() * 64), s1_lds_bytes<0>(), st, a));
         BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(g1, dim3(s1_blocks(groups, s1_waves<1>())), dim3(s1_waves<1>() * 64), s1_lds_bytes<1>(), st, a));
-    } else if constexpr (kTeam[C == 128 ? 2 : 3]) {
-        // wave-team kernels (stage34_f16.h): one workgroup of C/64 waves per token group, four / two of them per CU
-        a.scratch = T + (size_t)B * H * W * C;              // two parked tensors per wave, behind the stage's own t (T has room for 8 / 16 of them)
-        const dim3 grid((unsigned)((groups + kTmG - 1) / kTmG)), block(tm_waves<C>() * 64);   // kTmG token groups per workgroup
-        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL((stage_tm_kernel16<C, CIN, 0>), grid, block, tm_lds_bytes<C>(), st, a));
-        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL((stage_tm_kernel16<C, CIN, 1>), grid, block, tm_lds_bytes<C>(), st, a));
     } else {
         // channel-split kernels: one workgroup of C/32 waves per token group
         constexpr int G = cs_groups<C>();
@@ -534,9 +525,6 @@ int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
 #endif
         if ((rc = run_stage16<128, 64>(blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_tail23<128>(blob, 2, X3, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
-#if BALF_DEBUG_STOP
-        if (const char *e = getenv("BALF_DEBUG_STOP_STAGE"); e && atoi(e) == 3) return BALF_OK;
-#endif
         if ((rc = run_stage16<256, 128>(blob, 3, X4, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         HeadArgs ha{blob, kLayout.st[3], kLayout.head_w, kLayout.head_b, kLayout.head_alpha, kLayout.head_beta,
                     T, R, scale, nb, h8, w8,

@@ -38,20 +38,6 @@ constexpr int kGeluLogEntries = 3 * kGeluLogM + 1;
 // input X, fragment format in HBM) follows the format of the stage that CONSUMES it.
 constexpr bool kFmt32[kStages] = {true, true, false, false};
 constexpr bool kFmt32Head = false;
-// Stages whose grid / block kernels are the wave-team kernels of stage34_f16.h (v_mfma_f32_32x32x16_f16): their weights are
-// packed as 32x32 fragments too, but the stage's INPUT keeps the 16x16 fragment format in HBM (kFmt32 above is about that
-// format and about the consumers of it: the stage-2 / stage-3 tail kernels and the head kernel stay 16x16 kernels).  So
-//   * conv0 of such a stage is packed in the K order its 32x32 lanes find in a 16x16-format pixel (weights.hip:
-//     pack_frags32, `from16`), the token-mix matrix with stage 1's token order (token 2 n + p);
-//   * the weights the 16x16 consumers read are kept as 16x16 fragments: stage 3's conv0 / RCAB.conv1 / RCAB.conv2 a second
-//     time for its tail kernel (StageOff::t_*), stage 4's conv2 for the head kernel.
-#ifndef BALF_TEAM3
-#define BALF_TEAM3 1         // stage 3 on the wave-team kernels (0: the channel-split kernels of stage_cs_f16.h, for A/B builds)
-#endif
-#ifndef BALF_TEAM4
-#define BALF_TEAM4 1         // stage 4 likewise
-#endif
-constexpr bool kTeam[kStages] = {false, false, BALF_TEAM3 != 0, BALF_TEAM4 != 0};
 
 struct BranchOff {                // GridGmlpLayer / BlockGmlpLayer
     int ln_g, ln_b;               // .norm
@@ -73,7 +59,6 @@ struct StageOff {
     int se2_w, se2_b;             // calayer.excite.2 [C, C/4] plain
     int conv2_w, conv2_b;         // .conv2 [C, C] frags (stage 4 only; dead weight elsewhere)
     int r2_plain;                 // RCAB .conv2 again, plain row-major fp32 [C, C]: mean(conv2(h)) = conv2(mean(h)) in the SE kernel
-    int t_conv0_w, t_r1_w, t_r2_w; // (stage 3 only, split-f16 blob) 16x16-fragment copies for the stage's tail kernel (see kTeam)
 };
 
 struct Layout {
@@ -116,11 +101,6 @@ constexpr Layout make_layout() {
         S.se2_w = take(C * (C / 4)); S.se2_b = take(C);
         S.conv2_w = take(C * C); S.conv2_b = take(C);
         S.r2_plain = take(C * C);
-        if (s == 2 && kTeam[s]) {
-            S.t_conv0_w = take(C * Cin);
-            S.t_r1_w = take(C * C);
-            S.t_r2_w = take(C * C);
-        }
     }
     L.head_w = take(kHeadNPad * kC[3]);
     L.head_b = take(kHeadNPad);

@@ -107,11 +107,9 @@ __global__ __launch_bounds__(kT3Waves * 64, 1) void stage3_tail_kernel16(StageAr
             for (int i = threadIdx.x * 16; i < bytes; i += NTHR * 16)
                 *reinterpret_cast<uint4 *>(smem_raw + dst + i) = *reinterpret_cast<const uint4 *>(s + i);
         };
-        // (when the stage's branch kernels are the wave-team kernels, whose weights are 32x32 fragments, the blob holds these three
-        // a second time as 16x16 fragments: layout.h kTeam)
-        copy(kT3R1, kTeam[2] ? S.t_r1_w : S.r1_w, NT * kT3KS * 2048);
-        copy(kT3R2, kTeam[2] ? S.t_r2_w : S.r2_w, NT * kT3KS * 2048);
-        copy(kT3Conv0, kTeam[2] ? S.t_conv0_w : S.conv0_w, NT * kT3KI * 2048);
+        copy(kT3R1, S.r1_w, NT * kT3KS * 2048);
+        copy(kT3R2, S.r2_w, NT * kT3KS * 2048);
+        copy(kT3Conv0, S.conv0_w, NT * kT3KI * 2048);
         __syncthreads();                                         // the only barrier of the kernel
     }
     const unsigned char *wl = smem_raw + lane * 16;

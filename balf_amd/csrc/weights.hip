@@ -114,10 +114,7 @@ void pack_frags16(float *dst_region, const float *W, int N, int K, int Npad, boo
 //              from the transposed tile in LDS).
 // row(R, m) = 32 R + m, or for the token-mix matrix of stage 1 (`token_rows`) 2 m + R: output tile R holds the tokens the
 // lane columns of pixel tile R carry (token t = 2 n + p, stage1_f16.h; stage 2: token t = 32 R + n, stage2_f16.h).
-// `from16` (conv0 of the wave-team stages, layout.h kTeam): the B operand is read out of a 16x16-format pixel in HBM, whose
-// 16-byte chunk q of K-step-of-32 S holds channels 32 S + 16 (j >> 2) + 4 q + (j & 3); lane half h of K-step-of-16 s = 2 S + e
-// takes chunk q = 2 e + h, so its K-slot j carries channel 32 (s >> 1) + 16 (j >> 2) + 4 (2 (s & 1) + h) + (j & 3).
-void pack_frags32(float *dst_region, const float *W, int N, int K, int Npad, bool permuted, bool token_rows, bool from16 = false) {
+void pack_frags32(float *dst_region, const float *W, int N, int K, int Npad, bool permuted, bool token_rows) {
     _Float16 *dst = reinterpret_cast<_Float16 *>(dst_region);
     const int KS = K / 16;
     for (int R = 0; R < Npad / 32; ++R)
@@ -126,9 +123,7 @@ void pack_frags32(float *dst_region, const float *W, int N, int K, int Npad, boo
                 for (int j = 0; j < 8; ++j) {
                     const int m = lane & 31, h = lane >> 5;
                     const int n = token_rows ? 2 * m + R : 32 * R + m;
-                    const int k = from16     ? 32 * (s >> 1) + 16 * (j >> 2) + 4 * (2 * (s & 1) + h) + (j & 3)
-                                  : permuted ? 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)
-                                             : 16 * s + 8 * h + j;
+                    const int k = permuted ? 16 * s + 8 * (j >> 2) + 4 * h + (j & 3) : 16 * s + 8 * h + j;
                     const float w = n < N ? W[(size_t)n * K + k] : 0.0f;
                     const _Float16 hi = (_Float16)w;
                     const _Float16 lo = (_Float16)(w - (float)hi);
@@ -195,11 +190,10 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
     };
     for (int s = 0; s < kStages; ++s) {
         const int C = kC[s], Cin = kCin[s];
-        fmt32 = kFmt32[s] || kTeam[s];
+        fmt32 = kFmt32[s];
         const StageOff &S = kLayout.st[s];
         const float *const *t = tensors + s * kTensorsPerStage;
         if (s == 0) copy(blob + S.conv0_w, t[0], (size_t)C * Cin);
-        else if (f16 && kTeam[s] && !kFmt32[s]) pack_frags32(blob + S.conv0_w, t[0], C, Cin, C, true, false, /*from16=*/true);
         else pack(blob + S.conv0_w, t[0], C, Cin, C);
         copy(blob + S.conv0_b, t[1], C);
         std::vector<float> Wf, bf;
@@ -218,7 +212,7 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
             copy(blob + B.d1_b, bf.data(), 2 * C);
             copy(blob + B.gln_g, u[4], C);
             copy(blob + B.gln_b, u[5], C);
-            if (f16 && fmt32) pack_frags32(blob + B.mix_w, u[6], kTokens, kTokens, kTokens, false, /*token_rows=*/s == 0 || kTeam[s]);
+            if (f16 && fmt32) pack_frags32(blob + B.mix_w, u[6], kTokens, kTokens, kTokens, false, /*token_rows=*/s == 0);
             else if (f16) pack_frags16(blob + B.mix_w, u[6], kTokens, kTokens, kTokens, false);
             else pack_frags(blob + B.mix_w, u[6], kTokens, kTokens, kTokens);
             copy(blob + B.mix_b, u[7], kTokens);
@@ -233,19 +227,13 @@ extern "C" int balf_pack_weights(const float *const *tensors, int n_tensors, int
         pack(blob + S.r1_w, Wf.data(), C, C, C);
         copy(blob + S.r1_b, bf.data(), C);
         pack(blob + S.r2_w, t[32], C, C, C);
-        if (f16 && S.t_r1_w) {          // the 16x16 tail kernel of a wave-team stage (stage3_tail_f16.h)
-            pack_frags16(blob + S.t_conv0_w, t[0], C, Cin, C, true);
-            pack_frags16(blob + S.t_r1_w, Wf.data(), C, C, C, true);
-            pack_frags16(blob + S.t_r2_w, t[32], C, C, C, true);
-        }
         copy(blob + S.r2_b, t[33], C);
         copy(blob + S.r2_plain, t[32], C * C);
         copy(blob + S.se0_w, t[34], (size_t)(C / 4) * C);
         copy(blob + S.se0_b, t[35], C / 4);
         copy(blob + S.se2_w, t[36], (size_t)C * (C / 4));
         copy(blob + S.se2_b, t[37], C);
-        if (f16 && kTeam[s] && !kFmt32Head) pack_frags16(blob + S.conv2_w, t[38], C, C, C, true);   // read by the (16x16) head kernel
-        else pack(blob + S.conv2_w, t[38], C, C, C);
+        pack(blob + S.conv2_w, t[38], C, C, C);
         copy(blob + S.conv2_b, t[39], C);
     }
     const float *const *h = tensors + kStages * kTensorsPerStage;
