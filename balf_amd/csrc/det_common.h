@@ -1,6 +1,8 @@
 // Device helpers, argument structs and the workspace plan shared by the fp32 (detector.hip) and the
 // split-f16 (detector_f16.hip) implementations of the detector forward.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 #include "diag.h"
 #include "layout.h"
@@ -410,10 +412,22 @@ struct Plan {
     size_t off_U, off_T, off_R, off_X[3], off_partial, off_chunk, off_scale, total;
 };
 
+// Run-time knob: BALF_MB_MPIXELS = 1 .. 64 in the environment of the process overrides the compiled default, in
+// units of 2^20 padded pixels (16: half the workspace -- 7.4 GB instead of 14.8 GB at 1088x1920 -- for ~1 % of the throughput).
+// Read once: balf_forward_workspace_bytes, balf_forward_micro_batch and balf_forward must agree within a process.
+inline long mb_pixels() {
+    static const long v = [] {
+        const char *e = getenv("BALF_MB_MPIXELS");
+        const long m = e ? atol(e) : 0;
+        return (m >= 1 && m <= 64) ? (m << 20) : (long)BALF_MB_PIXELS;
+    }();
+    return v;
+}
+
 inline Plan make_plan(int B, int Hp, int Wp) {
     Plan p{};
     const long px = (long)Hp * Wp;
-    long mb = (long)BALF_MB_PIXELS / px;               // <= 33.5 Mpx of stage-1 activations in flight
+    long mb = mb_pixels() / px;                        // <= 33.5 Mpx of stage-1 activations in flight (default)
     if (mb < 1) mb = 1;
     if (mb > B) mb = B;
     p.mb = (int)mb;

@@ -467,7 +467,7 @@ extern "C" size_t balf_forward_workspace_bytes(int B, int Hp, int Wp) {
 }
 
 extern "C" int balf_forward_micro_batch(int B, int Hp, int Wp) {
-    if (B <= 0 || Hp <= 0 || Wp <= 0 || Hp % 64 || Wp % 64) return 0;
+    if (B <= 0 || Hp <= 0 || Wp <= 0 || Hp % 64 || Wp % 64 || (long)Hp * Wp > (1L << 25)) return 0;   // (a shape balf_forward refuses)
     return balf::make_plan(B, Hp, Wp).mb;
 }
 

@@ -162,13 +162,20 @@ __device__ __forceinline__ void s2_gelu(f16v (&t)[2]) {
 __device__ __forceinline__ void s2_post(unsigned addr, unsigned value) {
     asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(value) : "memory");
 }
+// INVARIANT the poll relies on: both waves of a pair run the SAME sequence of posts and polls -- `item`, `stride`, `pass` and the
+// trip count of the group loop are pair-uniform (they depend on blockIdx and wave >> 1 only), and no wave leaves the loop or
+// skips a pass on its own.  A future per-wave early-out would park its partner here for ever: keep every exit pair-uniform.
+// A wave that finds the counter not there yet sleeps 64 cycles before it looks again, so that its spin does not take issue
+// slots from the partner (which may sit on the same SIMD) it is waiting for.
 __device__ __forceinline__ void s2_poll(unsigned addr, unsigned target) {
     unsigned v;
-    do {
+    for (;;) {
         // (not a vector-ALU instruction: the LDS return writes v long after any MFMA in flight has read its operands)
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
         v = __builtin_amdgcn_readfirstlane(v);
-    } while ((int)(v - target) < 0);
+        if ((int)(v - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
 }
 
 #if BALF_S1_STRICT

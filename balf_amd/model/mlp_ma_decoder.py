@@ -167,6 +167,19 @@ class MLP_MA_DECODER(nn.Module):
     def _state_key(self, device):
         return self._weights_key(device) + (self.precision,)
 
+    def invalidate_packed(self) -> None:
+        """Drop the packed blobs and the split-f16 range verdict: the next forward re-packs the weights as they are NOW.
+
+        The cache key (``_weights_key``) notices in-place updates of the parameters themselves, ``load_state_dict``,
+        replaced parameters, ``p.data = other`` swaps and dtype / device moves.  It CANNOT see an in-place edit made
+        through ``p.data`` -- ``p.data.mul_(2)``, ``p.data.copy_(w)``, ``p.data.clamp_()`` -- because ``.data`` is an
+        alias with a version counter of its own (tests/test_host_api.py pins this).  Code that edits weights that way
+        (some EMA and weight-clipping helpers do) must call this method afterwards, or use ``with torch.no_grad():
+        p.mul_(2)``, which the key does see."""
+        self._packed = {}
+        self._fp16_verdict = None
+        self._effective = None
+
     def packed_weights(self, device, precision=None, _wkey=None) -> torch.Tensor:
         """The packed blob of the current weights for ``precision`` (default: the requested one) on ``device``."""
         precision = precision or self.precision

@@ -74,24 +74,52 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def allgather_keypoints(idx: torch.Tensor, score: torch.Tensor, count: torch.Tensor, group=None, force: bool = False):
-    """Every rank ends up with the keypoints of the whole batch, in rank order.  Slabs have the same
-    shape on every rank (equal shards; pad with ``-1`` rows otherwise).  A single-rank group returns its
-    inputs untouched unless ``force`` is set (then the collective runs anyway: the plumbing check of
-    SURVEY.md 8e on a one-GPU box)."""
+def allgather_keypoints(idx: torch.Tensor, score: torch.Tensor, count: torch.Tensor, group=None, force: bool = False,
+                        total: Optional[int] = None):
+    """Every rank ends up with the keypoints of the whole batch, in rank order.
+
+    ``total`` = the number of images of the whole batch when the ranks hold the UNEQUAL shards of
+    :func:`shard_range` (a batch that does not divide by the world size): every rank pads its slab to
+    ``ceil(total / world)`` rows (index -1, score 0, count 0), the collective moves equal shapes, and the
+    padding rows are dropped from the result.  Without ``total`` the shards must be equal (the shapes are
+    checked across the group first: ranks that disagree raise instead of hanging inside RCCL).
+    A single-rank group returns its inputs untouched unless ``force`` is set (then the collective runs
+    anyway: the plumbing check of SURVEY.md 8e on a one-GPU box)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return idx, score, count
     if dist.get_world_size(group) == 1 and not force:
         return idx, score, count
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     b, k = idx.shape
-    # one slab per rank: [B, K] indices, [B, K] score bits and [B] counts, packed as int32 so that the
+    if total is None:
+        rows = b
+        # equal shards are a precondition of all_gather_into_tensor: make a violation an error on every rank
+        mine = torch.tensor([b, k], dtype=torch.int64, device=idx.device)
+        seen = torch.empty(world * 2, dtype=torch.int64, device=idx.device)
+        dist.all_gather_into_tensor(seen, mine, group=group)
+        seen = seen.view(world, 2)
+        if not bool((seen == mine).all()):
+            raise ValueError(f"allgather_keypoints: slab shapes differ across ranks ({seen.tolist()}); pass total= for the "
+                             f"unequal shards of shard_range")
+        shard_rows = [b] * world
+    else:
+        rows = -(-total // world)
+        shard_rows = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+        if shard_rows[rank] != b:
+            raise ValueError(f"allgather_keypoints: rank {rank} of {world} holds {b} images, shard_range({total}) gives {shard_rows[rank]}")
+    # one slab per rank: [rows, K] indices, [rows, K] score bits and [rows] counts, packed as int32 so that the
     # step costs a single latency-bound collective
-    slab = torch.empty((b, 2 * k + 1), dtype=torch.int32, device=idx.device)
-    slab[:, :k] = idx
-    slab[:, k:2 * k] = score.view(torch.int32)
-    slab[:, 2 * k] = count
-    out = torch.empty((world * b, 2 * k + 1), dtype=torch.int32, device=idx.device)
+    slab = torch.empty((rows, 2 * k + 1), dtype=torch.int32, device=idx.device)
+    slab[:b, :k] = idx
+    slab[:b, k:2 * k] = score.view(torch.int32)
+    slab[:b, 2 * k] = count
+    if rows > b:
+        slab[b:, :k] = -1
+        slab[b:, k:] = 0
+    out = torch.empty((world * rows, 2 * k + 1), dtype=torch.int32, device=idx.device)
     dist.all_gather_into_tensor(out, slab, group=group)
+    if any(r != rows for r in shard_rows):                      # drop the padding rows of the short shards
+        keep = torch.cat([torch.arange(r * rows, r * rows + shard_rows[r], device=idx.device) for r in range(world)])
+        out = out.index_select(0, keep)
     return out[:, :k].contiguous(), out[:, k:2 * k].contiguous().view(torch.float32), out[:, 2 * k].contiguous()

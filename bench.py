@@ -57,13 +57,16 @@ PEAK_HBM_GBS = 8000.0
 def _newest_pmc_profile():
     import glob
     import re
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")),
-                   key=lambda f: int(re.search(r"r(\d+)_pmc", os.path.basename(f)).group(1)))
-    return found[-1] if found else os.path.join(ROOT, "profiles", "r3_pmc.json")
+    found = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")):
+        m = re.fullmatch(r"r(\d+)_pmc\.json", os.path.basename(f))      # (a stray file that merely matches the glob is skipped)
+        if m:
+            found.append((int(m.group(1)), f))
+    return max(found)[1] if found else os.path.join(ROOT, "profiles", "r3_pmc.json")
 
 
 PMC_PROFILE = _newest_pmc_profile()
-PMC_IMAGES_PER_LAUNCH = 16         # the shape the PMC passes are taken on (tools/pmc_run.sh: one micro-batch of 1088x1920)
+PMC_DEFAULT_SHAPE = {"images_per_launch": 16, "hp": 1088, "wp": 1920}   # profiles written before the shape was recorded in them
 C_STAGE = [32, 64, 128, 256]
 CIN_STAGE = [3, 32, 64, 128]
 
@@ -115,10 +118,14 @@ def kernel_flops_per_launch(name: str, mb: int, hp: int, wp: int) -> float:
 def pmc_profile(precision: str, mb: int, hp: int, wp: int):
     """The committed PMC passes (profiles/rN_pmc.json of the newest round, tools/pmc_json.py): per profile slot, HBM bytes per launch and the
     issue-slot accounting; None when they do not cover this shape."""
-    if not (os.path.isfile(PMC_PROFILE) and mb == PMC_IMAGES_PER_LAUNCH and (hp, wp) == (1088, 1920)):
+    if not os.path.isfile(PMC_PROFILE):
         return None
     try:
-        return json.load(open(PMC_PROFILE))["slots"][precision]
+        prof = json.load(open(PMC_PROFILE))
+        shape = prof.get("shape", PMC_DEFAULT_SHAPE)
+        if (mb, hp, wp) != (shape["images_per_launch"], shape["hp"], shape["wp"]):
+            return None                          # per-launch bytes and instruction counts of another launch size: not comparable
+        return prof["slots"][precision]
     except (KeyError, ValueError):
         return None
 
@@ -316,12 +323,17 @@ def stub_main(args, json_fd):
     if os.environ.get("BALF_BENCH_TEST_FAULT") == "hang-all":
         time.sleep(3600)
     b, k = args.batch_per_gpu, args.topk
+    total, lo = None, rank * b
+    if args.global_batch:                      # the unequal shards of pipeline.shard_range, padded inside the collective
+        total = args.global_batch
+        lo, hi = pipeline.shard_range(total, rank, world)
+        b = hi - lo
     g = torch.Generator().manual_seed(77 + rank)
     idx = torch.randint(0, 1 << 20, (b, k), generator=g, dtype=torch.int32)
     score, count = torch.rand((b, k), generator=g), torch.full((b,), k, dtype=torch.int32)
 
     def step():
-        return pipeline.allgather_keypoints(idx, score, count, force=True)
+        return pipeline.allgather_keypoints(idx, score, count, force=True, total=total)
     for _ in range(args.warmup):
         out = step()
     dist.barrier()
@@ -333,15 +345,17 @@ def stub_main(args, json_fd):
     t = torch.tensor([dt, -dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max, dt_min = float(t[0]), -float(t[1])
-    assert out[0].shape == (world * b, k) and torch.equal(out[0][rank * b:(rank + 1) * b], idx)
+    n_all = total if total is not None else world * b
+    assert out[0].shape == (n_all, k) and torch.equal(out[0][lo:lo + b], idx)
     if rank == 0:
+        b = n_all / world                      # (mean images per rank, for the line below)
         res = {"metric": "bench.py launcher plumbing (stub step: no detector, no GPU)", "stub": True,
                "value": world * b * args.steps / dt_max, "unit": "images/s", "n_gpus": world,
                "rccl_ranks": dist.get_world_size(), "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "none", "data": "synthetic",
                "per_rank_images_per_s": {"min": b * args.steps / dt_max, "max": b * args.steps / dt_min},
-               "config": {"workload": f"stub: {b} x {k} fake keypoints per rank, all-gather only", "global_batch": b * world,
+               "config": {"workload": f"stub: {b} x {k} fake keypoints per rank, all-gather only", "global_batch": n_all,
                           "parallelism": f"dp{world}"},
                "launched_by": "bench.py" if os.environ.get("BALF_BENCH_LAUNCHED") else "external launcher",
                "rank_env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}}
@@ -434,6 +448,9 @@ def main():
     ap.add_argument("--other-configs", type=int, default=1, help="also time the other BASELINE configurations (N = 1)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(cores, 32))")
     ap.add_argument("--batch-per-gpu", type=int, default=32)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="images of the WHOLE job instead of --batch-per-gpu; must divide by --gpus (the timed step gathers equal "
+                         "slabs; pipeline.allgather_keypoints(total=) pads unequal shards, which only the stub step exercises)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--topk", type=int, default=2000)
@@ -464,6 +481,11 @@ def main():
         # never report one GPU count under another's name: the scaling run divides by --gpus
         raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (plain "
                          f"`python bench.py --gpus {args.gpus}` does it itself) or pass --gpus {world}")
+    if args.global_batch and not args.stub_step:
+        if args.global_batch % world:
+            raise SystemExit(f"[bench] --global-batch {args.global_batch} does not divide by --gpus {world}: the measured step shards the "
+                             f"batch equally (weak scaling).  Give a multiple of {world}, or --batch-per-gpu")
+        args.batch_per_gpu = args.global_batch // world
     if args.stub_step:
         return stub_main(args, json_fd)
     n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU

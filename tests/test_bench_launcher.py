@@ -133,3 +133,18 @@ def test_the_whole_run_has_a_deadline():
                        env=_env(BALF_BENCH_TEST_FAULT="hang-all", BALF_BENCH_DEADLINE_S="3", BALF_BENCH_GRACE_S="1"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and r.stdout.strip() == "" and "did not finish within" in r.stderr, r.stderr[-1500:]
+
+
+def test_global_batch_that_does_not_divide():
+    """7 images on 3 ranks.  The stub step runs the padded collective of pipeline.allgather_keypoints(total=)
+    (shards of 3 + 2 + 2) and every rank checks its own rows in the gathered slab; the MEASURED step refuses such a batch."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--global-batch", "7"] + STUB, env=_env(OMP_NUM_THREADS="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _one_line(r.stdout)
+    assert res["n_gpus"] == 3 and res["config"]["global_batch"] == 7
+    # the measured step: one rank, WORLD_SIZE 2 in the environment, a batch of 5 -> refused before any GPU work
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--global-batch", "5"],
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not divide" in r.stderr, r.stderr[-2000:]

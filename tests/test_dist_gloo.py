@@ -46,6 +46,59 @@ def test_allgather_keypoints_world2():
     assert res == {0: True, 1: True}
 
 
+def _uneven_worker(rank, world, port, total, k, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = pipeline.shard_range(total, rank, world)
+        g = torch.Generator().manual_seed(99)
+        all_idx = torch.randint(0, 1 << 20, (total, k), generator=g, dtype=torch.int32)
+        all_sc = torch.rand((total, k), generator=g)
+        all_cnt = torch.randint(0, k + 1, (total,), generator=g, dtype=torch.int32)
+        idx, sc, cnt = pipeline.allgather_keypoints(all_idx[lo:hi].clone(), all_sc[lo:hi].clone(), all_cnt[lo:hi].clone(), total=total)
+        ok = torch.equal(idx, all_idx) and torch.equal(sc, all_sc) and torch.equal(cnt, all_cnt)
+        # without total= the unequal shards must be refused on EVERY rank (not hang, not gather garbage)
+        refused = False
+        try:
+            pipeline.allgather_keypoints(all_idx[lo:hi].clone(), all_sc[lo:hi].clone(), all_cnt[lo:hi].clone())
+        except ValueError:
+            refused = True
+        out_q.put((rank, bool(ok), refused))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_uneven(world, total):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, total, 11, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    uneven = total % world != 0
+    assert res == [(r, True, uneven) for r in range(world)], res
+
+
+def test_allgather_unequal_shards_world2_b5():
+    """A batch that does not divide by the world size: shards of 3 + 2 images, padded to 3 rows for the
+    collective, the padding stripped again."""
+    _run_uneven(2, 5)
+
+
+def test_allgather_unequal_shards_world3_b7():
+    _run_uneven(3, 7)
+
+
+def test_allgather_unequal_shards_world3_b2():
+    """Fewer images than ranks: one rank holds nothing."""
+    _run_uneven(3, 2)
+
+
 def test_allgather_is_identity_without_process_group():
     idx = torch.zeros((2, 5), dtype=torch.int32); sc = torch.zeros((2, 5)); cnt = torch.zeros(2, dtype=torch.int32)
     a, b, c = pipeline.allgather_keypoints(idx, sc, cnt)

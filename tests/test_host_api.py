@@ -246,3 +246,28 @@ def test_packed_weight_cache_key_notices_every_kind_of_change():
     m.precision = "fp32"
     changed()
     assert len(m._state_tensors()) == 167
+
+
+def test_data_alias_edits_need_invalidate_packed():
+    """an in-place edit THROUGH ``p.data`` is invisible to the cache key (``.data`` is an alias with its own version
+    counter) -- pinned here so that the documented remedy, ``invalidate_packed()``, stays the contract: it empties the blob cache
+    and the split-f16 verdict, so the next forward packs the edited weights."""
+    import torch
+    from balf_amd import arch
+    from balf_amd.model import get_model
+    m = get_model.load_model(arch.DEFAULT_MODEL_CFG).eval()
+    k = m._state_key("cpu")
+    m.down2.conv2.weight.data.mul_(2.0)
+    m.down1.conv[0].bias.data.copy_(torch.ones(32))
+    assert m._state_key("cpu") == k                      # the limitation: nothing moved that the key can see
+    with torch.no_grad():
+        m.down2.conv2.weight.mul_(0.5)                   # the same edit on the parameter itself IS seen
+    assert m._state_key("cpu") != k
+    blob = m.packed_weights("cpu")                       # (packing is host code: works without a GPU)
+    assert m._packed and m.packed_weights("cpu") is blob
+    m.down3.conv2.weight.data.mul_(3.0)
+    assert m.packed_weights("cpu") is blob               # stale, as documented ...
+    m.invalidate_packed()
+    assert not m._packed and m._fp16_verdict is None
+    fresh = m.packed_weights("cpu")
+    assert fresh is not blob and not torch.equal(fresh, blob)   # ... and re-packed from the edited weights after the call

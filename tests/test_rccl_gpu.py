@@ -61,8 +61,25 @@ def test_allgather_keypoints_single_rank_rccl():
 
 
 def _device_count():
-    import torch
-    return torch.cuda.device_count()           # (counting devices does not initialise the GPU)
+    """GPUs of this box WITHOUT touching HIP: torch.cuda.device_count() falls back to hipGetDeviceCount -- which
+    initialises the runtime in the pytest process -- when amdsmi is not importable, and every later subprocess would then be the
+    child of a GPU-initialised parent.  The KFD topology lists one node per agent; GPU nodes have a non-zero simd_count."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(base):
+            try:
+                props = dict(ln.split()[:2] for ln in open(os.path.join(base, d, "properties")) if len(ln.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    visible = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+    if visible is not None and visible.strip() != "":
+        n = min(n, len([v for v in visible.split(",") if v.strip() != ""]))
+    return n
 
 
 @pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs (the build's gpurun boxes have one; an 8-GPU node runs it)")

@@ -22,6 +22,11 @@ import re
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
+# the launch shape the passes were taken on (written by tools/pmc_run.sh; bench.py attaches the per-launch numbers to launches of
+# exactly this shape and to no other)
+shape = {"images_per_launch": 16, "hp": 1088, "wp": 1920}
+for _f in sorted(glob.glob(root + "/*/shape.json")):
+    shape = json.load(open(_f))
 
 
 def slot_of(kernel: str):
@@ -97,6 +102,8 @@ for prec in ("fp16", "fp32"):
             for key, name in (("SQ_INSTS_LDS", "lds_insts"), ("SQ_INSTS_VMEM", "vmem_insts"), ("SQ_INSTS_SALU", "salu_insts")):
                 if key in c:
                     d[name] = c[key]
+            if "SQ_VALU_MFMA_COEXEC_CYCLES" in c:
+                d["valu_mfma_coexec_share"] = c["SQ_VALU_MFMA_COEXEC_CYCLES"] / simd_cycles
             if "SQ_LDS_IDX_ACTIVE" in c:
                 d["lds_array_busy_share"] = c["SQ_LDS_IDX_ACTIVE"] / cu_cycles
                 d["lds_idx_active_cycles"] = c["SQ_LDS_IDX_ACTIVE"]
@@ -115,5 +122,5 @@ for prec in ("fp16", "fp32"):
 json.dump({"command": "tools/pmc_profile.sh: per precision three rocprofv3 --kernel-trace --pmc passes of "
                       "`python3 bench.py --steps 1 --warmup 1 --batch-per-gpu 16 --cpu-images 0 --other-steps 0 --other-configs 0` "
                       "(1088x1920, 16 images per launch): SQ counters + GRBM_GUI_ACTIVE, FETCH_SIZE, WRITE_SIZE",
-           "definitions": __doc__, "slots": res}, open(out, "w"), indent=1)
+           "shape": shape, "definitions": __doc__, "slots": res}, open(out, "w"), indent=1)
 print(out)

@@ -5,11 +5,14 @@ root="$(cd "$(dirname "$0")/.." && pwd)"
 out="$root/$1"; shift
 prec="${PREC:-fp16}"
 mkdir -p "$out"
+IMAGES=${PMC_IMAGES:-16}
+# the shape the counters belong to, recorded next to them (tools/pmc_json.py copies it into the profile, bench.py checks it)
+echo "{\"images_per_launch\": $IMAGES, \"hp\": 1088, \"wp\": 1920}" > "$out/shape.json"
 cd /tmp && export TMPDIR=/tmp
 export BALF_FP16_CHECK=0      # (the one-off split-f16 range check of a new checkpoint would add three tiny dispatches per kernel to the averages)
 i=0
 for ctrs in "$@"; do
-  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 "$root/bench.py" --steps 1 --warmup 1 --batch-per-gpu 16 --cpu-images 0 --other-steps 0 --other-configs 0 --no-single-rank-collective --precision "$prec" > /dev/null 2>"$out/pass$i.err"
+  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 "$root/bench.py" --steps 1 --warmup 1 --batch-per-gpu $IMAGES --cpu-images 0 --other-steps 0 --other-configs 0 --no-single-rank-collective --precision "$prec" > /dev/null 2>"$out/pass$i.err"
   i=$((i+1))
 done
 python3 "$root/tools/pmc_summary.py" "$out" > "$out/summary.txt"
