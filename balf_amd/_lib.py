@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("BALF_HIP_LIB", os.path.join(_HERE, "libbalf_hip.so"))
 OK = 0
 PREC_FP32, PREC_FP16 = 0, 1
 MAX_NMS_SIZE, MAX_TOPK = 32, 16384
+STATUS_SCORE, STATUS_RANGE, STATUS_SE, STATUS_WORDS = 0, 1, 2, 4      # include/balf_hip.h: balf_forward_status
 
 # name -> (restype, argtypes); kept in step with include/balf_hip.h (tests/test_abi.py checks)
 _vp, _i, _sz, _fp = C.c_void_p, C.c_int, C.c_size_t, C.c_void_p
@@ -32,6 +33,8 @@ PROTOTYPES = {
     "balf_forward_micro_batch": (_i, [_i, _i, _i]),
     "balf_forward": (_i, [_vp, _i, _fp, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
     "balf_forward_u8": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _fp, _fp, _vp, _sz, _vp]),
+    "balf_forward_status": (_i, [_vp, _i, _fp, _i, _i, _i, _fp, _fp, _vp, _sz, _vp, _vp]),
+    "balf_forward_u8_status": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _fp, _fp, _vp, _sz, _vp, _vp]),
     "balf_forward_stage_view_numel": (_sz, [_i, _i, _i, _i]),
     "balf_forward_stage_view": (_i, [_i, _vp, _sz, _i, _i, _i, _i, _fp, _vp]),
     "balf_window_nms": (_i, [_fp, _i, _i, _i, _i, _i, _fp, _vp]),

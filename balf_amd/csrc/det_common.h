@@ -290,7 +290,20 @@ struct StageArgs {
     float *partial;       // [B, wgs_per_image, C] channel sums of t (stage 1, fused tail: of the RCAB's hidden layer)
     const float *scale;   // stage-1 tail kernel only: [B, C] squeeze-excite scale
     float *out;           // stage-1 tail kernel only: next stage's input, fragment format [B, H/2, W/2, C]
+    int *status;          // tail kernels: optional status block (include/balf_hip.h: balf_forward_status), may be null
 };
+
+// Status words (include/balf_hip.h): plain stores of 1, system scope (the block may be pinned host memory); no atomics, the
+// library never clears a word.
+__device__ __forceinline__ void status_raise(int *status, int word) {
+    if (status) __hip_atomic_store(status + word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// running maximum of |v| over the values a kernel is about to split into f16 halves (NaN is ignored here: it reaches the
+// head kernel's check): two values per v_max3_f32
+__device__ __forceinline__ float range_max(float m, float a, float b) {
+    return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));
+}
+constexpr float kF16Max = 65504.0f;
 
 struct InputU8 {           // optional raw-image input of the forward (ch = 0: none)
     const unsigned char *p;
@@ -353,7 +366,7 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const float *__restrict_
 // kernel, stage1_f16.h); conv2 is linear, so mean(t) = conv2_w mean(h) + conv2_b.
 template <int C>
 __global__ __launch_bounds__(256) void se_kernel(const float *blob, StageOff S, const float *chunk, float inv_hw,
-                                                 float *scale, int hidden_sums) {
+                                                 float *scale, int hidden_sums, int *status) {
     __shared__ float s_mean[C];
     __shared__ float s_in[C];
     __shared__ float s_hid[C / 4];
@@ -381,6 +394,7 @@ __global__ __launch_bounds__(256) void se_kernel(const float *blob, StageOff S, 
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = blob[S.se2_b + c];
         for (int h = 0; h < C / 4; ++h) acc += blob[S.se2_w + c * (C / 4) + h] * s_hid[h];
+        if (!(fabsf(acc) < INFINITY)) status_raise(status, 2 /* BALF_STATUS_SE */);
         scale[(long)n * C + c] = 1.0f / (1.0f + expf(-acc));
     }
 }
@@ -396,6 +410,7 @@ struct HeadArgs {
     int B, h, w;             // 1/8 resolution
     float *logits;           // [B,65,h,w] or nullptr
     float *prob;             // [B,8h,8w]
+    int *status;             // optional status block (include/balf_hip.h: balf_forward_status), may be null
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -450,8 +465,8 @@ inline Plan make_plan(int B, int Hp, int Wp) {
 
 // entry points of the two implementations (detector.hip / detector_f16.hip)
 int forward_f32(const float *blob, const float *x, const InputU8 &u8, int B, int Hp, int Wp, float *logits, float *prob,
-                char *ws, const Plan &pl, hipStream_t st);
+                char *ws, const Plan &pl, int *status, hipStream_t st);
 int forward_f16(const float *blob, const float *x, const InputU8 &u8, int B, int Hp, int Wp, float *logits, float *prob,
-                char *ws, const Plan &pl, hipStream_t st);
+                char *ws, const Plan &pl, int *status, hipStream_t st);
 
 }  // namespace balf

@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
             sum += e;
         }
     sum = quarter_allreduce(sum);
+    if (!(sum > 0.0f && sum < INFINITY)) status_raise(A.status, 0 /* BALF_STATUS_SCORE */);
     const float inv = 1.0f / sum;
     const int Wp = 8 * A.w;
 #pragma unroll
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
 }
 
 template <int C, int CIN>
-int run_stage(const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
+int run_stage(int *status, const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
               float *partial, float *chunk, float *scale, hipStream_t st) {
     constexpr int P = StageP<C>::P;
     constexpr int lds = stage_lds_bytes<C, P>();
@@ -404,7 +405,7 @@ int run_stage(const float *blob, int s, const float *X, const InputU8 &u8, int B
     BALF_PROF(4 * s + 2, st, {
         hipLaunchKernelGGL(se_reduce_kernel<C>, dim3(B * kSeChunks), dim3(256), 0, st, partial, per_img, chunk);
         hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], chunk,
-                           1.0f / ((float)H * (float)W), scale, 0);
+                           1.0f / ((float)H * (float)W), scale, 0, status);
     });
     BALF_LAUNCH_CHECK();
     return BALF_OK;
@@ -425,7 +426,7 @@ int run_pool(int s, const float *T, const float *R, const float *scale, int B, i
 }  // namespace
 
 int forward_f32(const float *blob, const float *x_nchw_dev, const InputU8 &u8, int B, int Hp, int Wp, float *logits_dev,
-                float *prob_dev, char *ws, const Plan &pl, hipStream_t st) {
+                float *prob_dev, char *ws, const Plan &pl, int *status, hipStream_t st) {
     balf_prof::Chain prof_chain;       // the launches below follow each other on `st` with nothing in between
 
     float *U = reinterpret_cast<float *>(ws + pl.off_U), *T = reinterpret_cast<float *>(ws + pl.off_T),
@@ -441,17 +442,17 @@ int forward_f32(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
         InputU8 u8b = u8;
         if (u8.ch) u8b.p = u8.p + (size_t)b0 * u8.h * u8.w * u8.ch;
         int rc;
-        if ((rc = run_stage<32, 3>(blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<32, 3>(status, blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool<32>(0, T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
-        if ((rc = run_stage<64, 32>(blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<64, 32>(status, blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool<64>(1, T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
-        if ((rc = run_stage<128, 64>(blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<128, 64>(status, blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool<128>(2, T, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
-        if ((rc = run_stage<256, 128>(blob, 3, X4, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage<256, 128>(status, blob, 3, X4, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         HeadArgs ha{blob, kLayout.st[3], kLayout.head_w, kLayout.head_b, kLayout.head_alpha, kLayout.head_beta,
                     T, R, scale, nb, h8, w8,
                     logits_dev ? logits_dev + (size_t)b0 * kHeadN * h8 * w8 : nullptr,
-                    prob_dev + (size_t)b0 * Hp * Wp};
+                    prob_dev + (size_t)b0 * Hp * Wp, status};
         BALF_PROF(15, st,
                   hipLaunchKernelGGL(head_kernel, dim3((unsigned)((long)nb * h8 * w8 / 64)), dim3(256), 0, st, ha));
         BALF_LAUNCH_CHECK();
@@ -473,7 +474,7 @@ extern "C" int balf_forward_micro_batch(int B, int Hp, int Wp) {
 
 static int forward_common(const void *packed_dev, int precision, const float *x_nchw_dev, const balf::InputU8 &u8, int B,
                           int Hp, int Wp, float *logits_dev, float *prob_dev, void *workspace_dev,
-                          size_t workspace_bytes, void *stream) {
+                          size_t workspace_bytes, int *status_dev, void *stream) {
     if (!packed_dev || !prob_dev || !workspace_dev) return BALF_ERR_ARG;
     if (precision != BALF_PREC_FP32 && precision != BALF_PREC_FP16) return BALF_ERR_ARG;
     if (B <= 0 || Hp <= 0 || Wp <= 0) return BALF_ERR_ARG;
@@ -487,26 +488,40 @@ static int forward_common(const void *packed_dev, int precision, const float *x_
     const float *blob = static_cast<const float *>(packed_dev);
     char *ws = static_cast<char *>(workspace_dev);
     return precision == BALF_PREC_FP32
-               ? balf::forward_f32(blob, x_nchw_dev, u8, B, Hp, Wp, logits_dev, prob_dev, ws, pl, (hipStream_t)stream)
-               : balf::forward_f16(blob, x_nchw_dev, u8, B, Hp, Wp, logits_dev, prob_dev, ws, pl, (hipStream_t)stream);
+               ? balf::forward_f32(blob, x_nchw_dev, u8, B, Hp, Wp, logits_dev, prob_dev, ws, pl, status_dev, (hipStream_t)stream)
+               : balf::forward_f16(blob, x_nchw_dev, u8, B, Hp, Wp, logits_dev, prob_dev, ws, pl, status_dev, (hipStream_t)stream);
+}
+
+extern "C" int balf_forward_status(const void *packed_dev, int precision, const float *x_nchw_dev, int B, int Hp, int Wp,
+                                   float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
+                                   int *status_dev, void *stream) {
+    if (!x_nchw_dev) return BALF_ERR_ARG;
+    return forward_common(packed_dev, precision, x_nchw_dev, balf::InputU8{nullptr, 0, 0, 0, 0, 0}, B, Hp, Wp, logits_dev,
+                          prob_dev, workspace_dev, workspace_bytes, status_dev, stream);
 }
 
 extern "C" int balf_forward(const void *packed_dev, int precision, const float *x_nchw_dev, int B, int Hp, int Wp,
                             float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
                             void *stream) {
-    if (!x_nchw_dev) return BALF_ERR_ARG;
-    return forward_common(packed_dev, precision, x_nchw_dev, balf::InputU8{nullptr, 0, 0, 0, 0, 0}, B, Hp, Wp, logits_dev,
-                          prob_dev, workspace_dev, workspace_bytes, stream);
+    return balf_forward_status(packed_dev, precision, x_nchw_dev, B, Hp, Wp, logits_dev, prob_dev, workspace_dev,
+                               workspace_bytes, nullptr, stream);
 }
 
-extern "C" int balf_forward_u8(const void *packed_dev, int precision, const unsigned char *image_dev, int channels, int B,
-                               int H, int W, float *logits_dev, float *prob_dev, void *workspace_dev,
-                               size_t workspace_bytes, void *stream) {
+extern "C" int balf_forward_u8_status(const void *packed_dev, int precision, const unsigned char *image_dev, int channels,
+                                      int B, int H, int W, float *logits_dev, float *prob_dev, void *workspace_dev,
+                                      size_t workspace_bytes, int *status_dev, void *stream) {
     if (!image_dev || (channels != 1 && channels != 3) || H <= 0 || W <= 0) return BALF_ERR_ARG;
     // make_shape_even + mod_padding_symmetric(64) (test_utils.py:16-32): padded size and where the image lands
     const int He = H + (H & 1), We = W + (W & 1);
     const int Hp = He % 64 ? (He / 64 + 1) * 64 : He, Wp = We % 64 ? (We / 64 + 1) * 64 : We;
     const balf::InputU8 u8{image_dev, channels, H, W, (Hp - He) / 2, (Wp - We) / 2};
     return forward_common(packed_dev, precision, nullptr, u8, B, Hp, Wp, logits_dev, prob_dev, workspace_dev,
-                          workspace_bytes, stream);
+                          workspace_bytes, status_dev, stream);
+}
+
+extern "C" int balf_forward_u8(const void *packed_dev, int precision, const unsigned char *image_dev, int channels, int B,
+                               int H, int W, float *logits_dev, float *prob_dev, void *workspace_dev,
+                               size_t workspace_bytes, void *stream) {
+    return balf_forward_u8_status(packed_dev, precision, image_dev, channels, B, H, W, logits_dev, prob_dev, workspace_dev,
+                                  workspace_bytes, nullptr, stream);
 }

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
     const long o = pixel - (long)n * hw;
     const int i = (int)(o / A.w), j = (int)(o - (long)i * A.w);
 
+    float rng = 0.0f;                                                     // max |v| over everything this lane splits (status block)
     // ---- x2 = t * s + r of the wave's 16 pixels -> shared B fragments ----
     {
         h8 *slot = xs + wave * (KS * 2 * 64);
@@ -242,6 +243,8 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
                 const int kk = 4 * half + k4, c0 = 32 * kk + 4 * q;
                 const f4 v0 = tv[k4][0] * ldg4(A.scale + (long)n * C + c0) + rv[k4][0];
                 const f4 v1 = tv[k4][1] * ldg4(A.scale + (long)n * C + c0 + 16) + rv[k4][1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rng = range_max(rng, v0[r], v1[r]);
                 const HL v = split8(v0, v1);
                 slot[(kk * 2 + 0) * 64 + lane] = v.hi;
                 slot[(kk * 2 + 1) * 64 + lane] = v.lo;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
         for (int s2 = 0; s2 < 2; ++s2) {
             f4 v0 = f[2 * s2][p], v1 = f[2 * s2 + 1][p];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v0[r] = max0(v0[r]); v1[r] = max0(v1[r]); }
+            for (int r = 0; r < 4; ++r) { v0[r] = max0(v0[r]); v1[r] = max0(v1[r]); rng = range_max(rng, v0[r], v1[r]); }
             const HL v = split8(v0, v1);
             xs[(p * KS + 2 * wave + s2) * 2 * 64 + lane] = v.hi;
             xs[(p * KS + 2 * wave + s2) * 2 * 64 + 64 + lane] = v.lo;
@@ -355,6 +358,10 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
             sum += e;
         }
     sum = quarter_allreduce(sum);
+    // status block (include/balf_hip.h): a denominator that is not a positive finite number means a non-finite logit -- an operand
+    // somewhere upstream left the range of its f16 halves; an input of this kernel at or beyond the largest f16 says it is close
+    if (!(sum > 0.0f && sum < INFINITY)) status_raise(A.status, 0 /* BALF_STATUS_SCORE */);
+    if (rng >= kF16Max) status_raise(A.status, 1 /* BALF_STATUS_RANGE */);
     const float inv = 1.0f / sum;
     const int Wp = 8 * A.w;
 #pragma unroll
@@ -420,7 +427,7 @@ inline unsigned s1_blocks(long groups, int waves) {
 }
 
 template <int C, int CIN>
-int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
+int run_stage16(int *status, const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
                 float *partial, float *chunk, float *scale, hipStream_t st) {
     StageArgs a{blob, kLayout.st[s], X, u8.p, u8.ch, u8.h, u8.w, u8.top, u8.left, B, H, W, U, T, R, partial};
     const int rows_per_group = (C == 64) ? 2 : 1;           // partial-sum rows per token group (stage 2: one per wave half)
@@ -449,7 +456,7 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
     BALF_PROF(4 * s + 2, st, {
         hipLaunchKernelGGL(se_reduce_kernel<C>, dim3(B * kSeChunks), dim3(256), 0, st, partial, per_img, chunk);
         hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], chunk,
-                           1.0f / ((float)H * (float)W), scale, stage_fused<C>() ? 1 : 0);
+                           1.0f / ((float)H * (float)W), scale, stage_fused<C>() ? 1 : 0, status);
     });
     BALF_LAUNCH_CHECK();
     return BALF_OK;
@@ -458,10 +465,10 @@ int run_stage16(const float *blob, int s, const float *X, const InputU8 &u8, int
 // Tail of stages 2-3 (stage2_kernel16<2> / stage3_tail_kernel16, both persistent): the stage input X, x1 (in R) and the SE scale
 // -> the next stage's input.
 template <int C>
-int run_tail23(const float *blob, int s, const float *X, const float *R, const float *scale, int B, int H, int W, float *out,
+int run_tail23(int *status, const float *blob, int s, const float *X, const float *R, const float *scale, int B, int H, int W, float *out,
                hipStream_t st) {
     static_assert(C == 64 || C == 128, "stage 4 has no tail kernel: its consumer is the head kernel");
-    StageArgs a{blob, kLayout.st[s], X, nullptr, 0, 0, 0, 0, 0, B, H, W, nullptr, nullptr, const_cast<float *>(R), nullptr, scale, out};
+    StageArgs a{blob, kLayout.st[s], X, nullptr, 0, 0, 0, 0, 0, B, H, W, nullptr, nullptr, const_cast<float *>(R), nullptr, scale, out, status};
     const long groups = (long)B * (H / 8) * (W / 8);
     if constexpr (C == 64)      // every wave PAIR walks its own list of groups (stage2_f16.h)
         BALF_PROF(4 * s + 3, st, hipLaunchKernelGGL(stage2_kernel16<2>, dim3(s1_blocks(groups, s2_waves<2>() / 2)), dim3(s2_waves<2>() * 64), s2_lds_bytes<2>(), st, a));
@@ -472,10 +479,10 @@ int run_tail23(const float *blob, int s, const float *X, const float *R, const f
 }
 
 // Stage-1 tail (stage1_kernel16<2>): x1 (in R), the image and the SE scale -> the next stage's input.
-int run_tail16(const float *blob, const float *X, const InputU8 &u8, const float *R, const float *scale, int B, int H, int W,
+int run_tail16(int *status, const float *blob, const float *X, const InputU8 &u8, const float *R, const float *scale, int B, int H, int W,
                float *out, hipStream_t st) {
     StageArgs a{blob, kLayout.st[0], X, u8.p, u8.ch, u8.h, u8.w, u8.top, u8.left, B, H, W, nullptr, nullptr,
-                const_cast<float *>(R), nullptr, scale, out};
+                const_cast<float *>(R), nullptr, scale, out, status};
     auto k = u8.ch ? stage1_kernel16<2, true> : stage1_kernel16<2, false>;
     const long groups = (long)B * (H / 8) * (W / 8);
     BALF_PROF(3, st, hipLaunchKernelGGL(k, dim3(s1_blocks(groups, s1_waves<2>())), dim3(s1_waves<2>() * 64), s1_lds_bytes<2>(), st, a));
@@ -499,7 +506,7 @@ extern "C" int balf_debug_stamps(unsigned long long *sums /*[16*40]*/, unsigned 
 #endif
 
 int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, int B, int Hp, int Wp, float *logits_dev,
-                float *prob_dev, char *ws, const Plan &pl, hipStream_t st) {
+                float *prob_dev, char *ws, const Plan &pl, int *status, hipStream_t st) {
     if (const int rc = ensure_kernel_attributes(); rc != BALF_OK) return rc;
     balf_prof::Chain prof_chain;       // the launches below follow each other on `st` with nothing in between
 
@@ -516,20 +523,20 @@ int forward_f16(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
         InputU8 u8b = u8;
         if (u8.ch) u8b.p = u8.p + (size_t)b0 * u8.h * u8.w * u8.ch;
         int rc;
-        if ((rc = run_stage16<32, 3>(blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_tail16(blob, x, u8b, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
-        if ((rc = run_stage16<64, 32>(blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_tail23<64>(blob, 1, X2, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
+        if ((rc = run_stage16<32, 3>(status, blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_tail16(status, blob, x, u8b, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
+        if ((rc = run_stage16<64, 32>(status, blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_tail23<64>(status, blob, 1, X2, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;
 #if BALF_DEBUG_STOP
         if (const char *e = getenv("BALF_DEBUG_STOP_STAGE"); e && atoi(e) == 2) return BALF_OK;
 #endif
-        if ((rc = run_stage16<128, 64>(blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
-        if ((rc = run_tail23<128>(blob, 2, X3, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
-        if ((rc = run_stage16<256, 128>(blob, 3, X4, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_stage16<128, 64>(status, blob, 2, X3, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 4, Wp / 4, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+        if ((rc = run_tail23<128>(status, blob, 2, X3, R, scale, nb, Hp / 4, Wp / 4, X4, st)) != BALF_OK) return rc;
+        if ((rc = run_stage16<256, 128>(status, blob, 3, X4, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, h8, w8, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         HeadArgs ha{blob, kLayout.st[3], kLayout.head_w, kLayout.head_b, kLayout.head_alpha, kLayout.head_beta,
                     T, R, scale, nb, h8, w8,
                     logits_dev ? logits_dev + (size_t)b0 * kHeadN * h8 * w8 : nullptr,
-                    prob_dev + (size_t)b0 * Hp * Wp};
+                    prob_dev + (size_t)b0 * Hp * Wp, status};
         BALF_PROF(15, st,
                   hipLaunchKernelGGL(head_kernel16_ns,
                                      dim3((unsigned)((long)nb * h8 * w8 / 64)), dim3(256), 0, st, ha));

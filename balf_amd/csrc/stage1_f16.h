@@ -494,6 +494,7 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
     }
     const float2 a0 = *reinterpret_cast<const float2 *>(smem_raw + kS1Conv0 + lane * 8);   // conv0's A operands (loop-invariant)
 
+    unsigned long long sat = 0;                                  // (tail) lanes that saw a stage output at or beyond the largest f16
     for (; item < total; item += stride) {
         const Geo g = geo(nxt);
         if (item + stride < total) nxt = advance(nxt);           // (the last group re-requests its own pixels)
@@ -611,6 +612,10 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
                 const int pv = __builtin_amdgcn_update_dpp(up, mi, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
                 mx[r] = __builtin_fmaxf(m, __builtin_bit_cast(float, pv));
             }
+            // the stage's output, about to be split: status block.  The verdict lives in SCALAR registers (a lane mask per
+            // comparison, OR-ed): a running maximum in a vector register is one more than this kernel has at three waves per SIMD
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sat |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(mx[r]) >= kF16Max);
             // lanes n and n + 4 (n & 4 == 0) both hold pooled pixel (ty / 2, n & 3) of the 4 x 4 output block, so the FOUR lanes
             // of a pooled pixel -- two lane halves x two partners -- store its 128-byte row as two instructions of 64
             // contiguous bytes each (hi, lo), like the four lane quarters of the 16x16 layout did.  (Stored by the lanes n
@@ -813,4 +818,5 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         }
         }   // !TAIL
     }
+    if (TAIL && sat != 0) status_raise(A.status, 1 /* BALF_STATUS_RANGE */);
 }

@@ -337,6 +337,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
     const unsigned my_flags = (unsigned)(M::flags + wave * 8), peer_flags = (unsigned)(M::flags + (wave ^ 1) * 8);
     unsigned pass = 0;                                           // token-tile passes completed by this pair (wave-uniform)
 
+    float rng = 0.0f;                                            // (tail) max |v| over the stage's output (status block)
     for (; item < total; item += stride) {
         const Geo g = geo(nxt);
         const bool more = item + stride < total;
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
                 h2 hh, ll;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    rng = range_max(rng, sel[2 * i], sel[2 * i + 1]);       // the stage's output, about to be split (status block)
                     split_pair<BALF_S1_SPLIT_MIX>(sel[2 * i], sel[2 * i + 1], hh, ll);
                     o.hi[2 * i] = hh[0]; o.hi[2 * i + 1] = hh[1]; o.lo[2 * i] = ll[0]; o.lo[2 * i + 1] = ll[1];
                 }
@@ -680,4 +682,5 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
         }
         }   // !TAIL
     }
+    if (TAIL && rng >= kF16Max) status_raise(A.status, 1 /* BALF_STATUS_RANGE */);
 }

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(kT3Waves * 64, 1) void stage3_tail_kernel16(StageAr
     const int wx = (blockIdx.x >> 3) * NW + wave, xcd = blockIdx.x & 7;
     const int ty_l = 2 * ((li >> 2) & 1) + (li >> 3), tx0 = 2 * (li & 3);
 
+    float rng = 0.0f;                                            // max |v| over the stage's output (status block)
     for (int item = xcd * nx + wx; item < total; item += 8 * nx) {
         const int grp = item >> 1, w = item & 1;
         const int n = grp / per_img, rem = grp - n * per_img;
@@ -211,9 +212,12 @@ __global__ __launch_bounds__(kT3Waves * 64, 1) void stage3_tail_kernel16(StageAr
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[k][r] = lane_select(sm, mx[4 + k][r], mx[k][r]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rng = range_max(range_max(rng, o[k][0], o[k][1]), o[k][2], o[k][3]);   // about to be split (status block)
             const long opix = ((long)n * (H / 2) + (y >> 1)) * (W / 2) + (x0p >> 1);
             store_frag_px(A.out, opix, C, 2 * sel, q, split8(o[0], o[1]));
             store_frag_px(A.out, opix, C, 2 * sel + 1, q, split8(o[2], o[3]));
         }
     }
+    if (rng >= kF16Max) status_raise(A.status, 1 /* BALF_STATUS_RANGE */);
 }

@@ -92,6 +92,38 @@ def _down(cin, c, a):
     return d
 
 
+class _Fp16Guard:
+    """The status block of the split-f16 forwards on one device (include/balf_hip.h: balf_forward_status): four ints in PINNED
+    HOST memory that the kernels store into when a softmax denominator is not finite or a stage output reaches the largest
+    f16 -- the host reads them without a copy -- plus what is needed to repair the last call if it turns out to be flagged:
+    an event recorded behind it and weak references to its input and outputs."""
+
+    def __init__(self, device):
+        self.words = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32).pin_memory()
+        self.device = device
+        self.pending = None            # (event, weights key, call) of the last guarded forward, not yet looked at
+
+    def ptr(self) -> int:
+        return self.words.data_ptr()
+
+    def read_and_clear(self):
+        w = self.words.tolist()
+        if any(w):
+            self.words.zero_()
+        return w
+
+
+def _guard_mode() -> str:
+    """BALF_FP16_GUARD = lazy (default) | sync | off.  lazy: the status block of a split-f16 forward is looked at when the
+    NEXT forward of the module starts (or in fp16_guard_check()), never with a synchronisation on the hot path; sync: before
+    the forward returns (one stream synchronisation per call, the flagged batch is re-run before anyone sees it); off: the
+    kernels get no status block."""
+    m = os.environ.get("BALF_FP16_GUARD", "lazy")
+    if m not in ("lazy", "sync", "off"):
+        raise ValueError(f"BALF_FP16_GUARD must be lazy, sync or off, got {m!r}")
+    return m
+
+
 class MLP_MA_DECODER(nn.Module):
     def __init__(self, model_cfg, precision: str = "fp16"):
         super().__init__()
@@ -112,6 +144,7 @@ class MLP_MA_DECODER(nn.Module):
         self._packed = {}              # precision -> (weights key, device blob)
         self._fp16_verdict = None      # (weights key, precision the split-f16 request resolves to for these weights)
         self._effective = None
+        self._guard = {}               # device -> _Fp16Guard (status block of the split-f16 forwards, see _guarded_call)
 
     # ---- weights -> packed device blob -------------------------------------------------------
     @staticmethod
@@ -215,9 +248,16 @@ class MLP_MA_DECODER(nn.Module):
         the exact-fp32 kernels; if the score maps disagree or are not finite THESE WEIGHTS run on the fp32 kernels (still
         the HIP library, ~2.5x slower) and the module says so -- or raises with BALF_FP16_STRICT=1.  The requested
         precision is left alone: the next checkpoint is judged afresh."""
+        g = self._guard.get(device)
+        if g is not None and g.pending is not None and not getattr(self, "_validating", False):
+            self._guard_look(g, final=False)                     # lazy look at the previous call's status block (no wait)
         wkey = self._weights_key(device)
         prec = self.precision
-        if prec == "fp16" and not getattr(self, "_validating", False) and os.environ.get("BALF_FP16_CHECK", "1") != "0":
+        if prec == "fp16" and not getattr(self, "_validating", False) and self._fp16_verdict is not None \
+                and self._fp16_verdict[0] == wkey and self._fp16_verdict[1] == "fp32" \
+                and os.environ.get("BALF_FP16_CHECK", "1") == "0":
+            prec = "fp32"                                        # (a guard verdict holds even where the load-time probes are off)
+        elif prec == "fp16" and not getattr(self, "_validating", False) and os.environ.get("BALF_FP16_CHECK", "1") != "0":
             v = self._fp16_verdict
             if v is None or v[0] != wkey:
                 self._fp16_verdict = v = (wkey, self._check_fp16_range(device))
@@ -263,12 +303,82 @@ class MLP_MA_DECODER(nn.Module):
         prob = torch.empty((b, h, w), dtype=torch.float32, device=dev)
         logits = torch.empty((b, 65, h // 8, w // 8), dtype=torch.float32, device=dev) if want_logits else None
         nbytes = l.balf_forward_workspace_bytes(b, h, w)
-        ws = ops._workspace("forward", dev, nbytes)
-        with torch.cuda.device(dev):
-            check(l.balf_forward(blob.data_ptr(), self._code_of(prec), x.data_ptr(), b, h, w,
-                                 logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
-                                 ws.numel(), _lib.current_stream_ptr(dev)), "balf_forward")
+
+        def run(blob_, prec_, status):
+            ws = ops._workspace("forward", dev, nbytes)
+            with torch.cuda.device(dev):
+                check(l.balf_forward_status(blob_.data_ptr(), self._code_of(prec_), x.data_ptr(), b, h, w,
+                                            logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), status, _lib.current_stream_ptr(dev)), "balf_forward")
+        self._guarded_call(dev, prec, blob, run, (x, prob, logits))
         return {"logits": logits, "prob": prob}
+
+    # ---- the split-f16 path on inputs nobody has seen ----------------------
+    def _guarded_call(self, dev, prec, blob, run, tensors):
+        """Run one forward (``run(blob, precision, status pointer or None)``).  On the split-f16 path the kernels get the
+        module's status block; what it says is acted on according to BALF_FP16_GUARD (see _guard_mode):
+        a flagged batch is re-run on the exact-fp32 kernels INTO THE SAME OUTPUT TENSORS -- stream-ordered, so every later GPU
+        consumer sees the repaired values -- the module warns (BALF_FP16_STRICT=1: raises) and these weights run on the fp32
+        kernels from then on (effective_precision says so).  In lazy mode the repair happens when the next forward starts
+        and only if the caller still holds the flagged call's input and outputs; a host copy taken in between is not
+        recalled -- use BALF_FP16_GUARD=sync (or validate_fp16) where that matters."""
+        mode = _guard_mode()
+        if prec != "fp16" or mode == "off" or getattr(self, "_validating", False):
+            run(blob, prec, None)
+            return
+        g = self._guard.get(dev)
+        if g is None:
+            g = self._guard[dev] = _Fp16Guard(dev)
+        run(blob, prec, g.ptr())
+        import weakref
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        refs = tuple(weakref.ref(t) if t is not None else None for t in tensors)
+        g.pending = (ev, self._weights_key(dev), run, refs)
+        if mode == "sync":
+            ev.synchronize()
+            self._guard_look(g, final=True)
+
+    def _guard_look(self, g, final: bool):
+        """Look at the status block behind the pending call.  ``final``: the stream has passed it."""
+        pend = g.pending
+        if pend is None:
+            return
+        ev, wkey, run, refs = pend
+        if not final and not ev.query():
+            return                      # still running: the words are sticky, the next look sees them
+        g.pending = None
+        words = g.read_and_clear()
+        if not any(words):
+            return
+        # Any word is a reason to leave the split path: beyond 65504 the high half saturates and the low half alone (11 bits)
+        # carries the excess -- ~3e-4 relative instead of 2^-20 --, beyond ~1.3e5 the products turn into inf / NaN.
+        msg = ("an operand of the split-f16 path left the range of its f16 halves on a caller's input (status words "
+               f"score={words[0]} range={words[1]} se={words[2]}: non-finite score map / stage output >= 65504 / non-finite "
+               "squeeze-excite)")
+        if os.environ.get("BALF_FP16_STRICT") == "1":
+            raise BalfHipError(msg + "; use precision='fp32' for this checkpoint")
+        # these weights run on the exact-fp32 kernels from now on ...
+        dev = g.device
+        if self._weights_key(dev) == wkey:
+            self._fp16_verdict = (wkey, "fp32")
+        live = [r() if r is not None else None for r in refs]
+        repaired = False
+        if live[0] is not None and live[1] is not None and self._weights_key(dev) == wkey:
+            # ... and the flagged batch is computed again into the tensors the caller holds
+            run(self.packed_weights(dev, "fp32", wkey), "fp32", None)
+            repaired = True
+        self._effective = "fp32"
+        warnings.warn("balf_amd: " + msg + ("; that batch was re-run on the exact-fp32 kernels into the same output tensors"
+                                            if repaired else "; its outputs could not be repaired (input or outputs released)") +
+                      ", and this checkpoint runs on the fp32 kernels from now on (effective_precision='fp32')", RuntimeWarning)
+
+    def fp16_guard_check(self, synchronize: bool = True) -> None:
+        """Act on the status block of the last split-f16 forward now (see _guarded_call); ``synchronize`` waits for it."""
+        for g in self._guard.values():
+            if g.pending is not None and synchronize:
+                g.pending[0].synchronize()
+            self._guard_look(g, final=synchronize)
 
     def stage_view(self, b: int, h: int, w: int, device=None):
         """Validation aid: after ``forward`` / ``forward_u8`` of a batch whose PADDED shape is ``[b,3,h,w]`` on the current
@@ -341,9 +451,12 @@ class MLP_MA_DECODER(nn.Module):
         prob = torch.empty((b, hp, wp), dtype=torch.float32, device=dev)
         logits = torch.empty((b, 65, hp // 8, wp // 8), dtype=torch.float32, device=dev) if want_logits else None
         nbytes = l.balf_forward_workspace_bytes(b, hp, wp)
-        ws = ops._workspace("forward", dev, nbytes)
-        with torch.cuda.device(dev):
-            check(l.balf_forward_u8(blob.data_ptr(), self._code_of(prec), images.data_ptr(), ch, b, h, w,
-                                    logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
-                                    ws.numel(), _lib.current_stream_ptr(dev)), "balf_forward_u8")
+
+        def run(blob_, prec_, status):
+            ws = ops._workspace("forward", dev, nbytes)
+            with torch.cuda.device(dev):
+                check(l.balf_forward_u8_status(blob_.data_ptr(), self._code_of(prec_), images.data_ptr(), ch, b, h, w,
+                                               logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), status, _lib.current_stream_ptr(dev)), "balf_forward_u8")
+        self._guarded_call(dev, prec, blob, run, (images, prob, logits))
         return {"logits": logits, "prob": prob}

@@ -100,6 +100,32 @@ int balf_forward_u8(const void *packed_dev, int precision, const unsigned char *
                     int H, int W, float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
                     void *stream);
 
+/* The same two forwards with a STATUS WORD BLOCK: status_dev -> 4 ints, caller-owned, writable by the device (device memory, or
+ * pinned host memory mapped into the device's address space so that the host can look at it without a copy), zeroed by the
+ * caller.  The split-f16 path (BALF_PREC_FP16) carries every MFMA operand as two f16 halves: a value beyond +-65504
+ * saturates the high half and beyond ~1.3e5 turns into inf / NaN without any trap (csrc/split16.h).  With a status block the
+ * kernels report that, at no cost while nothing happens -- the library only ever STORES 1 into a word, it never clears one:
+ *   status[BALF_STATUS_SCORE] = 1   a pixel's softmax denominator was not a positive finite number (head kernel): the score
+ *                                   map of this call holds non-finite values or garbage;
+ *   status[BALF_STATUS_RANGE] = 1   a stage output (the next stage's input, the head's input or conv2's output) reached
+ *                                   |v| >= 65504: its high half saturated -- the low half alone (11 bits) carries the
+ *                                   excess, precision drops from 2^-20 to ~3e-4 relative, and beyond ~1.3e5 it overflows too;
+ *   status[BALF_STATUS_SE]    = 1   a squeeze-excite pre-activation was not finite (SE kernel);
+ *   status[3]                       reserved (never written).
+ * The words are valid once the stream has passed the call.  status_dev may be NULL (then these are balf_forward /
+ * balf_forward_u8).  The exact-fp32 path (BALF_PREC_FP32) has no operand range to leave and reports BALF_STATUS_SCORE only.
+ * Host mirror: MLP_MA_DECODER checks the block lazily and re-runs a flagged batch on the fp32 kernels. */
+#define BALF_STATUS_SCORE 0
+#define BALF_STATUS_RANGE 1
+#define BALF_STATUS_SE 2
+#define BALF_STATUS_WORDS 4
+int balf_forward_status(const void *packed_dev, int precision, const float *x_nchw_dev, int B, int Hp, int Wp,
+                        float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
+                        int *status_dev, void *stream);
+int balf_forward_u8_status(const void *packed_dev, int precision, const unsigned char *image_dev, int channels, int B,
+                           int H, int W, float *logits_dev, float *prob_dev, void *workspace_dev, size_t workspace_bytes,
+                           int *status_dev, void *stream);
+
 /* Validation aid (not part of the data path): the activation that crosses stage boundary `stage` of the forward that last
  * ran on `workspace_dev` with the same (precision, B, Hp, Wp), as plain fp32 NHWC in out_dev:
  *   stage 1..3  Down.forward's return value of down1..down3 (mlp_ma_decoder.py:223-244: after MaxPool2d), i.e. the next

@@ -327,3 +327,125 @@ def test_workspace_cache_is_bounded_per_stream():
         assert ops._workspace("forward", dev, 1 << 19) is a            # reused, not regrown
     torch.cuda.synchronize()
     ops.release_workspaces()
+
+
+def _scaled_checkpoint_and_images():
+    """A checkpoint whose stage outputs stay below the largest f16 on the three load-time probes (uniform noise, black, white) but
+    not on an image of SATURATED colour noise (every channel of every pixel 0 or 1: it drives more pixels to the corners of
+    the colour cube than uniform noise does, and its stage-4 peak is 1.4x the probes'): conv0 of stage 1 (weight and bias) is
+    scaled so that the threshold 65504 falls between the two.  Measured with the exact-fp32 kernels through stage_view."""
+    from balf_amd.model import get_model
+    sd0 = synth.synthetic_state_dict(cases.WEIGHT_SEED)
+    g = torch.Generator().manual_seed(1)
+    probes = torch.stack([torch.rand((3, 128, 128), generator=g), torch.zeros((3, 128, 128)), torch.ones((3, 128, 128))])
+    cands = torch.stack([(torch.rand((3, 128, 128), generator=torch.Generator().manual_seed(100 + i)) > 0.5).float() for i in range(3)])
+
+    def peak(sd, x):                                         # max |stage output| per image, exact-fp32 kernels
+        m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+        m.load_state_dict(sd)
+        m.precision = "fp32"
+        m = m.eval().to("cuda:0")
+        out = []
+        for i in range(x.shape[0]):
+            with torch.inference_mode():
+                m(x[i:i + 1].to("cuda:0"))
+                out.append(max(float(v.abs().max()) for v in m.stage_view(1, 128, 128)))
+        return out
+
+    def scaled(f):
+        sd = dict(sd0)
+        sd["down1.conv.0.weight"] = sd0["down1.conv.0.weight"] * f
+        sd["down1.conv.0.bias"] = sd0["down1.conv.0.bias"] * f
+        return sd
+    f0 = 1.0e3                                               # (large enough that the scaled residual path dominates the peaks)
+    pp, pc = peak(scaled(f0), probes), peak(scaled(f0), cands)
+    best = int(np.argmax(pc))
+    assert pc[best] > 1.1 * max(pp), ("no saturated-noise image peaks above the probes", pp, pc)
+    f = f0 * 65504.0 / float(np.sqrt(max(pp) * pc[best]))
+    sd = scaled(f)
+    pp2, pc2 = peak(sd, probes), peak(sd, cands[best:best + 1])
+    assert max(pp2) < 0.97 * 65504.0 < 65504.0 * 1.03 < pc2[0], (pp2, pc2)
+    return sd, cands[best:best + 1]
+
+
+@pytest.mark.parametrize("mode", ["lazy", "sync"])
+def test_status_block_catches_what_the_load_time_probes_miss(monkeypatch, mode):
+    """an operand beyond the f16 range on a CALLER'S image.  The three probes pass, so the checkpoint runs on the
+    split-f16 path; on the saturated-noise image a stage output passes 65504 and the kernels raise BALF_STATUS_RANGE in the module's
+    status block.  sync mode: the batch is re-run on the fp32 kernels before forward returns.  lazy mode: forward returns the
+    split path's output, the NEXT call finds the flag, warns, repairs the tensors the caller still holds and switches the
+    checkpoint to the fp32 kernels.  BALF_FP16_STRICT=1: raises instead."""
+    from balf_amd.model import get_model
+    from balf_amd._lib import BalfHipError
+    import warnings as W
+    sd, bright = _scaled_checkpoint_and_images()
+    monkeypatch.delenv("BALF_FP16_STRICT", raising=False)
+    monkeypatch.setenv("BALF_FP16_GUARD", mode)
+    m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m.load_state_dict(sd)
+    m = m.eval().to("cuda:0")
+    calm = cases.forward_input(1, 128, 128, 3).to("cuda:0")
+    with W.catch_warnings():
+        W.simplefilter("error")
+        m(calm)                                              # probes + an ordinary image: silent, split path
+    assert m.effective_precision == "fp16"
+    ref = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    ref.load_state_dict(sd)
+    ref.precision = "fp32"
+    ref = ref.eval().to("cuda:0")
+    xb = bright.to("cuda:0")
+    want = ref(xb, want_logits=False)["prob"]
+    if mode == "sync":
+        with pytest.warns(RuntimeWarning, match="left the range of its f16 halves"):
+            out = m(xb, want_logits=False)
+        assert torch.equal(out["prob"], want)                # re-run on the fp32 kernels before anyone saw it
+    else:
+        with W.catch_warnings():
+            W.simplefilter("error")
+            out = m(xb, want_logits=False)                   # nothing yet: no synchronisation on the hot path
+        torch.cuda.synchronize()
+        with pytest.warns(RuntimeWarning, match="re-run on the exact-fp32 kernels into the same output tensors"):
+            m(calm)                                          # the next call looks at the status block
+        assert torch.equal(out["prob"], want)                # ... and has repaired the tensor the caller still holds
+    assert m.precision == "fp16" and m.effective_precision == "fp32"
+    with W.catch_warnings():
+        W.simplefilter("error")
+        again = m(xb, want_logits=False)                     # from now on: fp32 kernels, silently
+    assert torch.equal(again["prob"], want)
+    # strict: raise instead of repairing
+    monkeypatch.setenv("BALF_FP16_STRICT", "1")
+    monkeypatch.setenv("BALF_FP16_GUARD", "sync")
+    m2 = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m2.load_state_dict(sd)
+    m2 = m2.eval().to("cuda:0")
+    m2(calm)
+    with pytest.raises(BalfHipError, match="left the range"):
+        m2(xb)
+
+
+def test_status_block_through_the_c_abi():
+    """balf_forward_status with a DEVICE status block, straight through ctypes: zero on an ordinary image, BALF_STATUS_RANGE on the
+    bright one; a NULL block is balf_forward."""
+    from balf_amd import _lib, ops
+    from balf_amd.model import get_model
+    sd, bright = _scaled_checkpoint_and_images()
+    m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m.load_state_dict(sd)
+    m = m.eval().to("cuda:0")
+    dev = torch.device("cuda:0")
+    blob = m.packed_weights(dev, "fp16")
+    l = _lib.lib()
+    ws = torch.empty(l.balf_forward_workspace_bytes(1, 128, 128), dtype=torch.uint8, device=dev)
+    prob = torch.empty((1, 128, 128), device=dev)
+    status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+    for x, expect in ((cases.forward_input(1, 128, 128, 3), 0), (bright, 1)):
+        status.zero_()
+        xg = x.to(dev).contiguous()
+        rc = l.balf_forward_status(blob.data_ptr(), _lib.PREC_FP16, xg.data_ptr(), 1, 128, 128, None, prob.data_ptr(), ws.data_ptr(),
+                                   ws.numel(), status.data_ptr(), _lib.current_stream_ptr(dev))
+        assert rc == 0
+        w = status.cpu().tolist()
+        assert w[_lib.STATUS_RANGE] == expect and w[3] == 0, w
+    rc = l.balf_forward_status(blob.data_ptr(), _lib.PREC_FP16, xg.data_ptr(), 1, 128, 128, None, prob.data_ptr(), ws.data_ptr(),
+                               ws.numel(), None, _lib.current_stream_ptr(dev))
+    assert rc == 0
