@@ -222,3 +222,40 @@ EXTRACT_CASES = {
     "e_100x130": (100, 130, 50, 50, 15, 15),
     "e_odd_201x333_nms5": (201, 333, 300, 51, 4, 5),
 }
+
+
+# ---- natural images and a synthetic poster (round 5; fixtures in natural.npz) ----
+# name -> (K, border, nms).  im1 / im2 are the two photographs the reference's demo runs on (/root/reference/media, decoded with
+# PIL by make_golden.py and stored as uint8 arrays); the poster is generated below.
+NATURAL_CASES = {"im1": (1000, 15, 15), "im2": (1000, 15, 15), "poster": (1000, 15, 15)}
+NATURAL_FULL_PROB = ("im1", "poster")       # cases whose whole reference score map is stored (identical-input NMS)
+
+
+def poster_u8():
+    """480 x 640 RGB uint8 with what photographs rarely have and screenshots / documents always do: constant black, white and
+    saturated-colour rectangles with hard edges (exact ties in the score map, NMS plateaus, all-zero neighbourhoods), a
+    one-pixel checkerboard, one-pixel lines, a smooth ramp, and a patch of noise."""
+    im = np.full((480, 640, 3), 128, np.uint8)
+    im[0:160, 0:200] = 0                                            # black
+    im[0:160, 200:400] = 255                                        # white
+    im[0:160, 400:480] = (255, 0, 0)
+    im[0:160, 480:560] = (0, 255, 0)
+    im[0:160, 560:640] = (0, 0, 255)
+    yy, xx = np.mgrid[0:160, 0:200]
+    im[160:320, 0:200] = (((yy + xx) & 1) * 255).astype(np.uint8)[..., None]      # one-pixel checkerboard
+    im[160:320, 200:400] = np.linspace(0, 255, 200).astype(np.uint8)[None, :, None]   # horizontal ramp
+    im[160:320, 400:640] = 255
+    im[160:320:16, 400:640] = 0                                     # one-pixel horizontal lines on white
+    im[160:320, 400:640:16] = 0                                     # ... and vertical ones
+    rng = np.random.default_rng(7)
+    im[320:480, 0:200] = rng.integers(0, 256, (160, 200, 3), dtype=np.uint8)      # noise
+    im[320:480, 200:400] = 0
+    im[360:440, 240:360] = 255                                      # a white box on black
+    im[320:480, 400:640] = (40, 40, 40)
+    for k in range(6):                                              # dark squares of shrinking size
+        s = 40 - 6 * k
+        im[340:340 + s, 410 + 38 * k:410 + 38 * k + s] = (200, 180, 20)
+    return im
+
+
+POSTER_FLAT = {"black": (20, 140, 20, 180), "white": (20, 140, 220, 380)}   # interiors (y0, y1, x0, x1) of two constant rectangles

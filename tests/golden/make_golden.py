@@ -18,6 +18,10 @@ What is recorded is data only -- inputs are regenerated from seeds, outputs are 
   repeatability.npz   compute_repeatability / apply_homography_to_points results; those two modules import
                       torchvision / cv2 / torchgeometry (absent offline), so the reference's own function bodies are
                       extracted with ast from the files under /root/reference and executed as they are
+  natural.npz         (round 5) the two photographs of /root/reference/media (decoded with PIL, stored as uint8 arrays: data) and
+                      a synthetic poster (cases.poster_u8): score-map samples, extract_detections and demo_match.detect results of
+                      the reference on them, the whole score map for two of them; `python tests/golden/make_golden.py natural`
+                      writes this file alone
   hardnet.npz         descriptors (+ per-layer activations of one patch) of the reference's HardNet class with the
                       seeded synthetic weights, on synthetic patches
 """
@@ -146,7 +150,52 @@ def make_torchgeometry_stub():
     return tgm
 
 
+def natural_section(m):
+    """Photographs and a poster through the reference's own callers."""
+    import types
+    from PIL import Image
+    extract, detect = ref_extract_detections(), ref_demo_detect()
+    nat, seen = {}, {}
+    hook = m.register_forward_hook(lambda mod, i, o: seen.__setitem__("prob", o["prob"][0].detach().numpy().copy()))
+    for name, (k, border, nms) in cases.NATURAL_CASES.items():
+        if name == "poster":
+            im = cases.poster_u8()
+        else:
+            im = np.asarray(Image.open(f"/root/reference/media/{name}.jpg").convert("RGB"))
+            nat[name + ".u8"] = im                       # the decoded pixels: data, not source
+        h, w = im.shape[:2]
+        pts, _ = extract(im / 255.0, m, "cpu", nms_size=nms, num_points=k, border_size=border)
+        prob = seen.pop("prob")
+        nat[name + ".pts"] = pts
+        nat[name + ".prob_s8"] = prob[::8, ::8].copy()
+        nat[name + ".prob_rows"] = prob[cases.CFG_ROWS(prob.shape[0])].copy()
+        nat[name + ".prob_mix"] = cases.cfg_mix(prob)
+        nat[name + ".prob_cellsum"] = cases.cfg_cellsum(prob)
+        if name in cases.NATURAL_FULL_PROB:
+            nat[name + ".prob"] = prob
+        # the NMS map the reference computes on the way (crop -> remove_borders -> apply_nms): survivors and exact ties
+        hp, wp = prob.shape
+        top, left = (hp - (h + (h & 1))) // 2, (wp - (w + (w & 1))) // 2
+        sm = RT.apply_nms(RT.remove_borders(prob[top:top + h, left:left + w], borders=border), nms)
+        nat[name + ".nms_survivors"] = np.int64((sm > 0).sum())
+        vals = np.sort(sm[sm > 0])
+        nat[name + ".nms_tied_survivors"] = np.int64((np.diff(vals) == 0).sum())
+        if name == "poster":
+            for reg, (y0, y1, x0, x1) in cases.POSTER_FLAT.items():
+                nat[f"{name}.flat_{reg}_survivors"] = np.int64((sm[y0:y1, x0:x1] > 0).sum())
+        args = types.SimpleNamespace(**dict(cases.DETECT_ARGS, sub_pixel=False))
+        res = detect(args, im, m, "cpu")
+        nat[name + ".detect_pts"] = np.asarray(res, dtype=np.float64)
+        print(name, im.shape, "survivors", int(nat[name + ".nms_survivors"]), "tied", int(nat[name + ".nms_tied_survivors"]),
+              "K-th score", float(pts[-1, 3]), "detect", nat[name + ".detect_pts"].shape)
+    hook.remove()
+    np.savez_compressed(os.path.join(HERE, "natural.npz"), **nat)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "natural":
+        natural_section(ref_model(cases.WEIGHT_SEED)[0])
+        return
     out = {}
     # ---------------- forward, small ----------------
     m, cfg = ref_model(cases.WEIGHT_SEED)
@@ -173,6 +222,8 @@ def main():
                 taps[f"{name}.{s}.sample"], taps[f"{name}.{s}.chansum"] = cases.stage_sample(v)
     np.savez_compressed(os.path.join(HERE, "forward_small.npz"), **fw)
     np.savez_compressed(os.path.join(HERE, "stage_taps.npz"), **taps)
+
+    natural_section(m)
 
     # ---------------- forward at a config size (strided samples + detections) ----------------
     # The score map is taken from inside the reference's own caller: extract_detections runs pad -> model -> crop ->

@@ -292,3 +292,26 @@ def test_evaluation_glue_oracle_matches_reference_golden():
     res = O.compute_repeatability_with_maximum_filter(es, ed, cases.HOMOGRAPHY, ms, md, cases.EVAL_CASE["nms"],
                                                       cases.EVAL_CASE["num_points"])
     assert np.allclose([float(np.asarray(v[0])) for v in res], g["eval.result"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["poster", "im1"])
+def test_natural_images_oracle_matches_reference(sd, name):
+    """Round 5: the oracle on a photograph and on the poster (natural.npz, recorded from the reference): the forward's score map
+    against the reference's samples, and the NMS / top-K restatement on the reference's own map against the reference's points
+    -- constant regions, hard edges and exact ties included."""
+    from tests.golden import cases
+    f = np.load(os.path.join(G, "natural.npz"))
+    im = cases.poster_u8() if name == "poster" else f[name + ".u8"]
+    h, w = im.shape[:2]
+    k, border, nms = cases.NATURAL_CASES[name]
+    pts, prob = O.extract_detections(sd, im / 255.0, nms_size=nms, num_points=k, border_size=border)
+    assert np.abs(prob[::8, ::8] - f[name + ".prob_s8"]).max() < 1e-6
+    assert np.abs(cases.cfg_mix(prob) - f[name + ".prob_mix"]).max() < 1e-6
+    assert np.abs(prob - f[name + ".prob"]).max() < 1e-6
+    idx, sc = O.detect_from_prob(f[name + ".prob"], h, w, border, nms, k)
+    ref = f[name + ".pts"]
+    ri = (ref[:, 1] * w + ref[:, 0]).astype(np.int64)
+    o = np.argsort(ri)
+    assert np.array_equal(np.sort(idx), ri[o]) and np.array_equal(sc[np.argsort(idx)].astype(np.float64), ref[o, 3])
+    sm = O.apply_nms(O.remove_borders(f[name + ".prob"][(prob.shape[0] - h - (h & 1)) // 2:, :][:h, :w], border), nms)
+    assert int((sm > 0).sum()) == int(f[name + ".nms_survivors"])
