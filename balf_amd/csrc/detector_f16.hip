@@ -189,12 +189,23 @@ __device__ unsigned long long g_stamp_cnt[16];
             else atomicAdd(&g_stamp_cnt[STAMP_KID], 1ull);                                              \
         }                                                                                               \
     } while (0)
+// the head kernel's phases: an array of its own (the sixteen rows above are taken by the stage kernels)
+__device__ unsigned long long g_head_stamp_sum[40];
+__device__ unsigned long long g_head_stamp_cnt;
+#define STAMPV_FLUSH_HEAD()                                                                             \
+    do {                                                                                                \
+        if (threadIdx.x < 40) {                                                                         \
+            if (threadIdx.x > 0) atomicAdd(&g_head_stamp_sum[threadIdx.x], (unsigned long long)sv_vec); \
+            else atomicAdd(&g_head_stamp_cnt, 1ull);                                                    \
+        }                                                                                               \
+    } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMPV_DECL
 #define STAMPV(i)
 #define STAMPV_FLUSH()
+#define STAMPV_FLUSH_HEAD()
 #endif
 // add the value of lane (l + n) mod 16 of the same 16-lane row (DPP row_ror): 4 steps = sum over the row in every lane
 template <int N>
@@ -215,6 +226,8 @@ __device__ __forceinline__ float row_ror_add(float v) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
     constexpr int C = 256, KS = 8, HT = kHeadNPad / 16;
+    STAMPV_DECL;
+    STAMPV(0);
     __shared__ __attribute__((aligned(16))) h8 xs[4 * KS * 2 * 64];          // [tile][K-step][hi|lo][lane]: 64 KiB
     const int lane = threadIdx.x & 63, q = lane >> 4, li = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -251,7 +264,9 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
             }
         }
     }
+    STAMPV(1);   // t, r, scale loaded; x2 split and staged
     __syncthreads();
+    STAMPV(2);   // barrier
 
     // ---- conv2: row tiles 4w .. 4w+3 x four pixel tiles; weight fragments one K-step ahead in registers ----
     f4 f[4][4];
@@ -304,7 +319,27 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    STAMPV(3);   // conv2 (384 MFMAs per wave, weights from L2)
     __syncthreads();                                  // everyone is done reading x2: the buffer takes the conv2 output
+    STAMPV(4);   // barrier
+    f4 z[HT][1];
+    // (the head Linear's bias, weight pointers and first weight fragments: requested here, in front of the relu / split / barrier
+    // section, which covers their L2 round trip)
+    f4 za[4], zb;                                       // row tile `wave` x pixel tiles 0..3; row tile 4 x pixel tile `wave`
+    {
+        const f4 ba = ldg4(blob + A.head_b + 16 * wave + 4 * q);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) za[p] = ba;
+        zb = ldg4(blob + A.head_b + 64 + 4 * q);
+    }
+    const char *wb = reinterpret_cast<const char *>(blob + A.head_w) + lane * 16;
+    auto wload = [&](HL (&a)[2], int kk) {              // [0]: row tile `wave`, [1]: row tile 4
+        const char *p0 = wb + ((size_t)wave * KS + kk) * 2048, *p1 = wb + ((size_t)4 * KS + kk) * 2048;
+        a[0].hi = *reinterpret_cast<const h8 *>(p0); a[0].lo = *reinterpret_cast<const h8 *>(p0 + 1024);
+        a[1].hi = *reinterpret_cast<const h8 *>(p1); a[1].lo = *reinterpret_cast<const h8 *>(p1 + 1024);
+    };
+    HL a0[2];
+    wload(a0, 0);
     // relu -> B fragments of the head Linear: this wave's 4 row tiles are K-steps 2w, 2w+1 of every pixel tile
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -317,20 +352,61 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
             xs[(p * KS + 2 * wave + s2) * 2 * 64 + lane] = v.hi;
             xs[(p * KS + 2 * wave + s2) * 2 * 64 + 64 + lane] = v.lo;
         }
+    STAMPV(5);   // relu, split, staged
     __syncthreads();
+    STAMPV(6);   // barrier
 
-    // ---- head Linear 256 -> 65 (padded to 80) on the wave's own pixel tile, BatchNorm(eval), softmax, pixel shuffle ----
-    f4 z[HT][1];
-    init_bias(z, blob + A.head_b, q);
+    // ---- head Linear 256 -> 65 (padded to 80 = five row tiles), split by OUTPUT rows like conv2 ----
+    // (Until round 5 every wave ran all five row tiles on its own pixel tile and pulled all 80 KB of head weights through L2
+    // for 16 pixels: 120 MFMAs behind eight exposed L2 round trips -- 16.5 k of the workgroup's 54 k cycles for 1.9 k cycles
+    // of matrix work, profiles/r5_stamps_head.txt.)  Wave w computes row tile w for ALL four pixel tiles (96 MFMAs on 16 KB
+    // of weights) and row tile 4 for its own pixel tile (24 MFMAs, 16 KB that the four waves read together); the logits then
+    // cross the waves through LDS -- the B-fragment buffer is free once every wave has left the Linear -- so that BatchNorm,
+    // softmax and the pixel shuffle find a pixel's 80 values in the four lanes that held them before.
     {
-        const h8 *slot = xs + wave * (KS * 2 * 64);
-        gemm16<HT, 1>(z, blob + A.head_w, 0, KS, 0, KS, lane, [&](int kk, int) {
-            HL v;
-            v.hi = slot[(kk * 2 + 0) * 64 + lane];
-            v.lo = slot[(kk * 2 + 1) * 64 + lane];
-            return v;
-        });
+        auto compute = [&](const HL (&a)[2], int kk) {
+            HL b[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                b[p].hi = xs[(p * KS + kk) * 2 * 64 + lane];
+                b[p].lo = xs[(p * KS + kk) * 2 * 64 + 64 + lane];
+            }
+            HL bw;                                           // the wave's own pixel tile (wave-uniform index: a plain LDS read)
+            bw.hi = xs[(wave * KS + kk) * 2 * 64 + lane];
+            bw.lo = xs[(wave * KS + kk) * 2 * 64 + 64 + lane];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) if (!BALF_DROP_WLO) za[p] = mfma16(a[0].lo, b[p].hi, za[p]);
+            if (!BALF_DROP_WLO) zb = mfma16(a[1].lo, bw.hi, zb);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) za[p] = mfma16(a[0].hi, b[p].lo, za[p]);
+            zb = mfma16(a[1].hi, bw.lo, zb);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) za[p] = mfma16(a[0].hi, b[p].hi, za[p]);
+            zb = mfma16(a[1].hi, bw.hi, zb);
+        };
+        HL a1[2];
+        for (int kk = 0; kk < KS; kk += 2) {
+            wload(a1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a0, kk);
+            __builtin_amdgcn_sched_barrier(0);
+            wload(a0, kk + 2 < KS ? kk + 2 : kk);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(a1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                    // everyone is done with the B fragments: the buffer takes the logits
+        // zs[pixel 0..63][channel 0..79], 84 floats per pixel (16-byte accesses of 16 lanes a pixel apart: conflict-free)
+        float *zs = reinterpret_cast<float *>(xs);
+        constexpr int ZP = 84;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f4 *>(zs + (16 * p + li) * ZP + 16 * wave + 4 * q) = za[p];
+        *reinterpret_cast<f4 *>(zs + (16 * wave + li) * ZP + 64 + 4 * q) = zb;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < HT; ++t) z[t][0] = *reinterpret_cast<const f4 *>(zs + (16 * wave + li) * ZP + 16 * t + 4 * q);
     }
+    STAMPV(7);   // head Linear (120 MFMAs per wave) + logits through LDS
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
@@ -345,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
             }
         }
     }
+    STAMPV(8);   // BatchNorm, maximum, logits stored
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.0f;
@@ -364,12 +441,15 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
     if (rng >= kF16Max) status_raise(A.status, 1 /* BALF_STATUS_RANGE */);
     const float inv = 1.0f / sum;
     const int Wp = 8 * A.w;
+    STAMPV(9);   // 20 exponentials per lane, sums, status
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const f4 pr = z[t][0] * inv;
         float *dst = A.prob + ((long)n * 8 * A.h + 8 * i + 2 * t + (q >> 1)) * Wp + 8 * j + 4 * (q & 1);
         *reinterpret_cast<f4 *>(dst) = pr;
     }
+    STAMPV(10);  // normalise, pixel shuffle, prob stored
+    STAMPV_FLUSH_HEAD();
 }
 
 #include "stage1_f16.h"
@@ -493,6 +573,16 @@ int run_tail16(int *status, const float *blob, const float *X, const InputU8 &u8
 }  // namespace
 
 #if BALF_STAMPS
+extern "C" int balf_debug_head_stamps(unsigned long long *sums /*[40]*/, unsigned long long *cnt /*[1]*/, int reset) {
+    if (hipMemcpyFromSymbol(sums, HIP_SYMBOL(g_head_stamp_sum), sizeof(g_head_stamp_sum)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_head_stamp_cnt), sizeof(g_head_stamp_cnt)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[40];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_head_stamp_sum), z, sizeof(g_head_stamp_sum)) != hipSuccess) return -1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_head_stamp_cnt), z, sizeof(g_head_stamp_cnt)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 extern "C" int balf_debug_stamps(unsigned long long *sums /*[16*40]*/, unsigned long long *cnt /*[16]*/, int reset) {
     if (hipMemcpyFromSymbol(sums, HIP_SYMBOL(g_stamp_sum), sizeof(g_stamp_sum)) != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_stamp_cnt), sizeof(g_stamp_cnt)) != hipSuccess) return -1;

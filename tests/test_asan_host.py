@@ -1,6 +1,6 @@
 """The HOST side of libbalf_hip.so under AddressSanitizer + UndefinedBehaviorSanitizer:
 weight packer, workspace planners, argument checks, state-tensor table, status plumbing -- everything tests/test_abi.py and
-tests/test_host_api.py drive without a GPU -- run against a separately built library (BALF_ASAN=1 balf_amd/csrc/build.sh:
+tests/test_host_api.py drive without a GPU -- run against a separately built library (balf_amd/csrc/build_asan.sh:
 host code instrumented, device code as usual; GPU sanitizers are not available on this pool) in a child process that preloads
 the sanitizer runtime.  A heap overflow in pack_frags*, a misaligned or out-of-range access in make_plan or a signed overflow in
 an argument check aborts the child."""
@@ -29,7 +29,7 @@ def test_host_entry_points_under_asan_ubsan():
     src = os.path.join(ROOT, "balf_amd", "csrc")
     newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith((".hip", ".h")))
     if not os.path.isfile(ASAN_LIB) or os.path.getmtime(ASAN_LIB) < newest:
-        subprocess.check_call(["bash", os.path.join(src, "build.sh")], env=dict(os.environ, BALF_ASAN="1"))
+        subprocess.check_call(["bash", os.path.join(src, "build_asan.sh")])
     out = subprocess.run(["ldd", ASAN_LIB], capture_output=True, text=True).stdout
     assert "libclang_rt.asan" in out, "the instrumented library does not link the sanitizer runtime"
     env = dict(os.environ, LD_PRELOAD=rt, BALF_HIP_LIB=ASAN_LIB,
