@@ -265,10 +265,9 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
         }
     }
     STAMPV(1);   // t, r, scale loaded; x2 split and staged
-    __syncthreads();
-    STAMPV(2);   // barrier
-
     // ---- conv2: row tiles 4w .. 4w+3 x four pixel tiles; weight fragments one K-step ahead in registers ----
+    // (bias and the first K-step's fragments are requested in FRONT of the barrier that publishes x2: an L2 round trip less
+    // behind it)
     f4 f[4][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -276,16 +275,21 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) f[t][p] = b;
     }
-    {
-        const char *wb = reinterpret_cast<const char *>(blob + A.off.conv2_w) + ((size_t)(4 * wave) * KS) * 2048 + lane * 16;
-        auto wload = [&](HL (&a)[4], int kk) {
+    const char *wb2 = reinterpret_cast<const char *>(blob + A.off.conv2_w) + ((size_t)(4 * wave) * KS) * 2048 + lane * 16;
+    auto wload2 = [&](HL (&a)[4], int kk) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const char *p = wb + ((size_t)t * KS + kk) * 2048;
-                a[t].hi = *reinterpret_cast<const h8 *>(p);
-                a[t].lo = *reinterpret_cast<const h8 *>(p + 1024);
-            }
-        };
+        for (int t = 0; t < 4; ++t) {
+            const char *p = wb2 + ((size_t)t * KS + kk) * 2048;
+            a[t].hi = *reinterpret_cast<const h8 *>(p);
+            a[t].lo = *reinterpret_cast<const h8 *>(p + 1024);
+        }
+    };
+    HL c0[4];
+    wload2(c0, 0);
+    __syncthreads();
+    STAMPV(2);   // barrier
+    {
+        auto wload = wload2;
         auto compute = [&](const HL (&a)[4], int kk) {
             HL b[4];
 #pragma unroll
@@ -307,7 +311,8 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
                 for (int p = 0; p < 4; ++p) f[t][p] = mfma16(a[t].hi, b[p].hi, f[t][p]);
         };
         HL a0[4], a1[4];
-        wload(a0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a0[t] = c0[t];
         for (int kk = 0; kk < KS; kk += 2) {
             wload(a1, kk + 1);
             __builtin_amdgcn_sched_barrier(0);
