@@ -488,8 +488,14 @@ def main():
         args.batch_per_gpu = args.global_batch // world
     if args.stub_step:
         return stub_main(args, json_fd)
+    # Rehearsal (tests/test_rccl_gpu.py on a one-GPU box): all ranks share cuda:0 and the group is gloo -- everything the N > 1
+    # step does except RCCL itself (rank offsets into the synthetic batch, the gathered-slab checks, max-over-ranks timing,
+    # the JSON fields).  The line says so and is not a measurement.
+    rehearsal = os.environ.get("BALF_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU
-    if n_dev < max(world, local_rank + 1):
+    if n_dev < (1 if rehearsal else max(world, local_rank + 1)):
         raise SystemExit(f"[bench] rank {rank}: {n_dev} GPU(s) visible, {world} ranks asked for: refusing to report "
                          f"n_gpus={world} from fewer devices")
     if not torch.cuda.is_available():
@@ -502,7 +508,26 @@ def main():
     if world > 1:
         if "MASTER_PORT" not in os.environ:
             raise SystemExit("[bench] MASTER_PORT is not set: the ranks of one run must agree on it")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            _real_gather = dist.all_gather_into_tensor
+
+            def _gather_through_host(out, inp, group=None):          # gloo moves host memory: stage the slabs there
+                o = torch.empty(out.shape, dtype=out.dtype)
+                _real_gather(o, inp.cpu(), group=group)
+                out.copy_(o)
+            dist.all_gather_into_tensor = _gather_through_host
+            _real_all_gather = dist.all_gather
+
+            def _all_gather_through_host(outs, inp, group=None):
+                tmp = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+                _real_all_gather(tmp, inp.cpu(), group=group)
+                for o, t_ in zip(outs, tmp):
+                    o.copy_(t_)
+            dist.all_gather = _all_gather_through_host
+            collective_note = "REHEARSAL: gloo through host memory, all ranks on cuda:0 (not RCCL, not a measurement)"
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         have_group = True
     elif not args.no_single_rank_collective:
         # one GPU: run the path's collective anyway on a single-rank RCCL group (SURVEY.md 8e caveat), so that the step
@@ -738,8 +763,10 @@ def main():
             collective_note = ("all_gather_into_tensor of [B,2K+1] int32 keypoint slabs (RCCL)"
                                + ("" if world > 1 else ", single-rank group") if have_group else "none")
         res = {
-            "metric": ("images/sec + keypoints/sec on 1080p gray (detector forward + NMS + top-K); NMS index match vs CPU ref"
+            "metric": ("REHEARSAL (ranks share one GPU, gloo): not a measurement" if rehearsal else
+                       "images/sec + keypoints/sec on 1080p gray (detector forward + NMS + top-K); NMS index match vs CPU ref"
                        if build_flags.startswith("release") else "INVALID: diagnostic library build (timing ablation, wrong results)"),
+            "rehearsal": rehearsal,
             "value": ips, "unit": "images/s", "keypoints_per_s": ips * kp_per_image,
             "keypoints_per_image": kp_per_image,
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if have_group else 0,

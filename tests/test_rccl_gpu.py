@@ -101,3 +101,26 @@ def test_allgather_two_ranks():
     assert res["gathered_slabs_identical"] is True and res["config"]["global_batch"] == 64
     assert res["rank_env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert res["value"] > 0 and res["per_rank_images_per_s"]["min"] > 0
+
+
+def test_two_ranks_on_one_gpu_rehearsal():
+    """Everything the N = 2 step of bench.py does EXCEPT RCCL, on a one-GPU box (BALF_BENCH_REHEARSAL=1: both ranks on cuda:0,
+    gloo through host memory): the launcher starts two ranks, each runs forward + NMS + top-K on ITS shard of the synthetic
+    batch (images rank * b ...), the slabs are gathered, every rank verifies that all ranks hold the same gathered slabs with
+    its own shard at its rows, the time is the maximum over the ranks, rank 0 prints one line -- marked as a rehearsal, never as
+    a measurement.  The RCCL form of the same step waits for a box with two GPUs (test_allgather_two_ranks)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["BALF_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch-per-gpu", "3", "--height", "480", "--width", "640", "--topk", "1000",
+                        "--other-configs", "0", "--other-steps", "0", "--cpu-images", "0"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["rehearsal"] is True and res["metric"].startswith("REHEARSAL")
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["launched_by"] == "bench.py"
+    assert res["gathered_slabs_identical"] is True and res["config"]["global_batch"] == 6
+    assert res["keypoints_per_image"] == 1000.0 and res["per_rank_images_per_s"]["min"] > 0
