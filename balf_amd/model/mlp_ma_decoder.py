@@ -99,7 +99,9 @@ class _Fp16Guard:
     an event recorded behind it and weak references to its input and outputs."""
 
     def __init__(self, device):
-        self.words = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32).pin_memory()
+        with torch.inference_mode(False):   # (a NORMAL tensor even when the first forward runs under torch.inference_mode(): an
+            # inference tensor could not be cleared from outside that mode later)
+            self.words = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32).pin_memory()
         self.device = device
         self.pending = None            # (event, weights key, call) of the last guarded forward, not yet looked at
 
@@ -264,6 +266,7 @@ class MLP_MA_DECODER(nn.Module):
             prec = v[1]
         self._code_of(prec)
         self._effective = prec
+        self._last_wkey = wkey           # (the guard below tags the call with it: one key computation per forward)
         return prec, self.packed_weights(device, prec, wkey)
 
     def _check_fp16_range(self, device) -> str:
@@ -334,7 +337,7 @@ class MLP_MA_DECODER(nn.Module):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         refs = tuple(weakref.ref(t) if t is not None else None for t in tensors)
-        g.pending = (ev, self._weights_key(dev), run, refs)
+        g.pending = (ev, self._last_wkey, run, refs)
         if mode == "sync":
             ev.synchronize()
             self._guard_look(g, final=True)
@@ -373,12 +376,18 @@ class MLP_MA_DECODER(nn.Module):
                                             if repaired else "; its outputs could not be repaired (input or outputs released)") +
                       ", and this checkpoint runs on the fp32 kernels from now on (effective_precision='fp32')", RuntimeWarning)
 
-    def fp16_guard_check(self, synchronize: bool = True) -> None:
-        """Act on the status block of the last split-f16 forward now (see _guarded_call); ``synchronize`` waits for it."""
+    def fp16_guard_check(self, synchronize: bool = True) -> bool:
+        """Act on the status block of the last split-f16 forward now (see _guarded_call); ``synchronize`` waits for it.
+        Returns True when a flag was found and acted on -- a caller that has already copied that call's results to the host
+        (pipeline.extract_detections, demo_match.detect: the reference's one-image-per-call pattern) repeats its call then."""
+        hit = False
         for g in self._guard.values():
             if g.pending is not None and synchronize:
                 g.pending[0].synchronize()
+            before = self._fp16_verdict
             self._guard_look(g, final=synchronize)
+            hit = hit or (self._fp16_verdict is not before and self._fp16_verdict is not None and self._fp16_verdict[1] == "fp32")
+        return hit
 
     def stage_view(self, b: int, h: int, w: int, device=None):
         """Validation aid: after ``forward`` / ``forward_u8`` of a batch whose PADDED shape is ``[b,3,h,w]`` on the current

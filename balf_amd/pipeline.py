@@ -59,7 +59,12 @@ def extract_detections(image_RGB_norm, model, device, cell_size=8, nms_size=15, 
     h, w = image_RGB_norm.shape[0], image_RGB_norm.shape[1]
     x = pad_batch(image_RGB_norm[None]).to(device)
     idx, score, count, prob = detect_batch(model, x, h, w, border_size, nms_size, num_points)
-    n = int(count[0])
+    n = int(count[0])                  # (a device-to-host read: the stream has passed the forward)
+    # one image per call, results on the host at once: the split-f16 status block is final here, for free -- a flagged call
+    # is repeated on the fp32 kernels before anything is returned (mlp_ma_decoder.py: _guarded_call)
+    if getattr(model, "fp16_guard_check", None) is not None and model.fp16_guard_check(synchronize=False):
+        idx, score, count, prob = detect_batch(model, x, h, w, border_size, nms_size, num_points)
+        n = int(count[0])
     i = idx[0, :n].cpu().numpy().astype(np.int64)
     pts = np.empty((n, 4), dtype=np.float64)
     pts[:, 0], pts[:, 1], pts[:, 2], pts[:, 3] = i % w, i // w, 1.0, score[0, :n].cpu().numpy()

@@ -423,6 +423,40 @@ def test_status_block_catches_what_the_load_time_probes_miss(monkeypatch, mode):
         m2(xb)
 
 
+def test_single_image_callers_repeat_a_flagged_call(monkeypatch):
+    """The reference's calling pattern -- one image per call, the result on the host at once (train_utils.extract_detections,
+    demo_match.detect) -- needs no synchronisation of its own to be safe: the mirrors look at the status block after their
+    device-to-host read and repeat a flagged call on the fp32 kernels before returning."""
+    from balf_amd import pipeline
+    from balf_amd.demo import demo_match
+    from balf_amd.model import get_model
+    from types import SimpleNamespace
+    sd, bright = _scaled_checkpoint_and_images()
+    monkeypatch.delenv("BALF_FP16_STRICT", raising=False)
+    monkeypatch.delenv("BALF_FP16_GUARD", raising=False)         # the default: lazy
+    img = bright[0].permute(1, 2, 0).contiguous().numpy().astype(np.float64)          # [H,W,3] in {0, 1}
+    ref = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    ref.load_state_dict(sd)
+    ref.precision = "fp32"
+    ref = ref.eval().to("cuda:0")
+    want, _ = pipeline.extract_detections(img, ref, "cuda:0", nms_size=15, num_points=200, border_size=15)
+    m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m.load_state_dict(sd)
+    m = m.eval().to("cuda:0")
+    with pytest.warns(RuntimeWarning, match="left the range of its f16 halves"):
+        got, _ = pipeline.extract_detections(img, m, "cuda:0", nms_size=15, num_points=200, border_size=15)
+    assert np.array_equal(got, want) and m.effective_precision == "fp32"
+    m2 = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    m2.load_state_dict(sd)
+    m2 = m2.eval().to("cuda:0")
+    args = SimpleNamespace(**dict(cases.DETECT_ARGS, sub_pixel=False))
+    im_u8 = (img * 255).astype(np.uint8)
+    want_d = demo_match.detect(args, im_u8, ref, "cuda:0")
+    with pytest.warns(RuntimeWarning, match="left the range of its f16 halves"):
+        got_d = demo_match.detect(args, im_u8, m2, "cuda:0")
+    assert np.array_equal(got_d, want_d)
+
+
 def test_status_block_through_the_c_abi():
     """balf_forward_status with a DEVICE status block, straight through ctypes: zero on an ordinary image, BALF_STATUS_RANGE on the
     bright one; a NULL block is balf_forward."""
