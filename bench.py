@@ -629,8 +629,8 @@ def main():
             # per VALU instruction, 12.5 per 16x16x32 f16 MFMA beside vector work / 32 per 16x16x4 f32 MFMA;
             # tools/ubench/mfma_valu_mix.hip) over the SIMD cycles of the launch in the same profiled run
             roof["issue"] = {k_: slot[k_] for k_ in ("valu_insts", "mfma_insts", "issue_share", "valu_busy_share",
-                                                     "mfma_busy_share", "wave_wait_share", "wave_issue_stall_share",
-                                                     "waves") if k_ in slot}
+                                                     "mfma_busy_share", "valu_mfma_coexec_share", "wave_wait_share",
+                                                     "wave_issue_stall_share", "waves") if k_ in slot}
         share = (slot or {}).get("issue_share", 0.0)
         if max(f_m, f_h) < 0.5 and share > max(f_m, f_h):
             roof.update({"bound": "valu_issue", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h,
@@ -751,6 +751,11 @@ def main():
     latency = power = None
     if world == 1 and args.other_configs and (h, w, b) == (1080, 1920, 32):
         power = power_state_under_load(step, dev)
+        if power is not None:
+            # the forward is bound by the package power limit: joule per image is the figure a kernel change has
+            # to move -- package power under load / images per second of this rank
+            power["joule_per_image"] = power["package_power_w"] / (head["images_per_s"] / world)
+            power["note"] += "; joule_per_image = package power / this rank's images per second"
         latency = [single_image_latency(model, dev, hh, ww, kk) for (hh, ww, kk) in ((480, 640, 1000), (1080, 1920, 2000))]
 
     if rank == 0:
