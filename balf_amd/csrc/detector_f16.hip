@@ -284,8 +284,9 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
             a[t].lo = *reinterpret_cast<const h8 *>(p + 1024);
         }
     };
-    HL c0[4];
-    wload2(c0, 0);
+    HL cr[3][4];                                        // a ring of three K-steps of this wave's four row tiles (96 registers)
+    wload2(cr[0], 0);
+    wload2(cr[1], 1);
     __syncthreads();
     STAMPV(2);   // barrier
     {
@@ -310,24 +311,18 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) f[t][p] = mfma16(a[t].hi, b[p].hi, f[t][p]);
         };
-        HL a0[4], a1[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a0[t] = c0[t];
-        for (int kk = 0; kk < KS; kk += 2) {
-            wload(a1, kk + 1);
+        for (int kk = 0; kk < KS; ++kk) {
+            if (kk + 2 < KS) wload(cr[(kk + 2) % 3], kk + 2);     // two K-steps (768 cycles of this wave's matrix work) ahead
             __builtin_amdgcn_sched_barrier(0);
-            compute(a0, kk);
-            __builtin_amdgcn_sched_barrier(0);
-            wload(a0, kk + 2 < KS ? kk + 2 : kk);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(a1, kk + 1);
+            compute(cr[kk % 3], kk);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     STAMPV(3);   // conv2 (384 MFMAs per wave, weights from L2)
     __syncthreads();                                  // everyone is done reading x2: the buffer takes the conv2 output
     STAMPV(4);   // barrier
-    f4 z[HT][1];
+    f4 z[HT][1], bn_al[HT], bn_be[HT];
     // (the head Linear's bias, weight pointers and first weight fragments: requested here, in front of the relu / split / barrier
     // section, which covers their L2 round trip)
     f4 za[4], zb;                                       // row tile `wave` x pixel tiles 0..3; row tile 4 x pixel tile `wave`
@@ -343,8 +338,9 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
         a[0].hi = *reinterpret_cast<const h8 *>(p0); a[0].lo = *reinterpret_cast<const h8 *>(p0 + 1024);
         a[1].hi = *reinterpret_cast<const h8 *>(p1); a[1].lo = *reinterpret_cast<const h8 *>(p1 + 1024);
     };
-    HL a0[2];
-    wload(a0, 0);
+    HL ar[4][2];                                        // a ring of four K-steps (64 registers: conv2's accumulators die below)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wload(ar[kk], kk);
     // relu -> B fragments of the head Linear: this wave's 4 row tiles are K-steps 2w, 2w+1 of every pixel tile
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -389,16 +385,18 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
             for (int p = 0; p < 4; ++p) za[p] = mfma16(a[0].hi, b[p].hi, za[p]);
             zb = mfma16(a[1].hi, bw.hi, zb);
         };
-        HL a1[2];
-        for (int kk = 0; kk < KS; kk += 2) {
-            wload(a1, kk + 1);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            compute(ar[kk & 3], kk);
             __builtin_amdgcn_sched_barrier(0);
-            compute(a0, kk);
+            if (kk + 4 < KS) wload(ar[kk & 3], kk + 4);     // four K-steps (~1 300 cycles of matrix work of the CU's waves) ahead
             __builtin_amdgcn_sched_barrier(0);
-            wload(a0, kk + 2 < KS ? kk + 2 : kk);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(a1, kk + 1);
-            __builtin_amdgcn_sched_barrier(0);
+        }
+        // BatchNorm's scale and shift of the lane's 20 channels: requested in front of the exchange below
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            bn_al[t] = ldg4(blob + A.head_alpha + 16 * t + 4 * q);
+            bn_be[t] = ldg4(blob + A.head_beta + 16 * t + 4 * q);
         }
         __syncthreads();                                    // everyone is done with the B fragments: the buffer takes the logits
         // zs[pixel 0..63][channel 0..79], 84 floats per pixel (16-byte accesses of 16 lanes a pixel apart: conflict-free)
@@ -415,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel16_ns(HeadArgs A) {
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
-        const f4 al = ldg4(blob + A.head_alpha + 16 * t + 4 * q), be = ldg4(blob + A.head_beta + 16 * t + 4 * q);
+        const f4 al = bn_al[t], be = bn_be[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = 16 * t + 4 * q + r;
