@@ -174,7 +174,7 @@ __device__ __forceinline__ void s2_poll(unsigned addr, unsigned target) {
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
         v = __builtin_amdgcn_readfirstlane(v);
         if ((int)(v - target) >= 0) break;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(1);          // (A/B on one box: 4.55-4.57 ms per 32 images with it, 4.53-4.56 without)
     }
 }
 
