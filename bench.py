@@ -634,7 +634,9 @@ def main():
         share = (slot or {}).get("issue_share", 0.0)
         if max(f_m, f_h) < 0.5 and share > max(f_m, f_h):
             roof.update({"bound": "valu_issue", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": f_h,
-                         "note": "neither roof above 0.5: vector/matrix instruction issue is the limit (see issue.issue_share); "
+                         "note": "neither roof above 0.5: vector/matrix instruction issue is the limit (see issue.issue_share) -- at the "
+                                 "clock the package power cap allows (power_state_under_load; the same instruction streams on zero "
+                                 "operands hold 2.36 GHz of 2.4 at 1125 W and run 20 % faster: profiles/r5_power_zero.txt); "
                                  "achieved/peak/frac are the HBM figures"})
         elif f_m >= f_h:
             roof.update({"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": f_m})
