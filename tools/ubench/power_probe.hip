@@ -6,6 +6,8 @@
 //   5: v_pk_fma_f32   6: the operand split of a pair
 //   (round 4: data movement)  7: ds_read_b128 from LDS (1 KB per wave-instruction)   8: global_load_dwordx4 from an L2-resident
 //   1 MB window (L1 thrashed: every CU sweeps 64 KB per iteration)   9: the same from a 4 GB buffer (HBM)
+//   (round 5: what an int8 correction product would cost)  10: v_mfma_i32_16x16x64_i8   11: v_mfma_i32_32x32x32_i8 (twice the MACs of
+//   the f16 instruction of the same shape in the same cycles)
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/power_probe.hip -o tools/ubench/power_probe
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -41,6 +43,35 @@ __global__ __launch_bounds__(512) void kmem(float *out, const char *buf, unsigne
         }
     }
     out[blockIdx.x * 512 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+
+typedef int i4x __attribute__((ext_vector_type(4)));
+typedef int i16x __attribute__((ext_vector_type(16)));
+template <int MODE>
+__global__ __launch_bounds__(512) void ki8(float *out, int iters) {
+    i4x a[2], b[2];
+    unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    for (int v = 0; v < 2; ++v)
+        for (int i = 0; i < 4; ++i) {
+            s = s * 1664525u + 1013904223u; a[v][i] = (int)s;
+            s = s * 1664525u + 1013904223u; b[v][i] = (int)s;
+        }
+    i4x acc[8];
+    i16x big[4];
+    for (int j = 0; j < 8; ++j) acc[j] = i4x{0, 0, 0, 0};
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 16; ++i) big[j][i] = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (MODE == 10) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a[j & 1]), "v"(b[j & 1]));
+            if (MODE == 11 && (j & 1) == 0) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(big[j >> 1]) : "v"(a[(j >> 1) & 1]), "v"(b[(j >> 1) & 1]));
+        }
+    }
+    int r = 0;
+    for (int j = 0; j < 8; ++j) r += acc[j][0];
+    for (int j = 0; j < 4; ++j) r += big[j][0];
+    out[blockIdx.x * 512 + threadIdx.x] = (float)r;
 }
 
 template <int MODE>
@@ -116,6 +147,8 @@ int main(int argc, char **argv) {
             case 7: hipLaunchKernelGGL(kmem<7>, dim3(256), dim3(512), 0, 0, out, buf, span, iters); break;
             case 8: hipLaunchKernelGGL(kmem<8>, dim3(256), dim3(512), 0, 0, out, buf, span, iters); break;
             case 9: hipLaunchKernelGGL(kmem<9>, dim3(256), dim3(512), 0, 0, out, buf, span, iters); break;
+            case 10: hipLaunchKernelGGL(ki8<10>, dim3(256), dim3(512), 0, 0, out, iters); break;
+            case 11: hipLaunchKernelGGL(ki8<11>, dim3(256), dim3(512), 0, 0, out, iters); break;
             case 0: hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, out, iters); break;
             case 1: hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, out, iters); break;
             case 2: hipLaunchKernelGGL(k<2>, dim3(256), dim3(512), 0, 0, out, iters); break;
@@ -137,12 +170,13 @@ int main(int argc, char **argv) {
         el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } while (el < secs);
     // per iteration and wave: 8 MFMA(16x16x32) | 4 MFMA(32x32x16) | 128 fma | 32 exp | 8 MFMA + 48 fma;  2048 waves
-    const double per_iter[10] = {8, 4, 128, 32, 8, 64, 32, 8, 8, 8};
+    const double per_iter[12] = {8, 4, 128, 32, 8, 64, 32, 8, 8, 8, 8, 4};
     const double rate = n * (double)iters * per_iter[mode] * 2048 / el;
-    const char *what[10] = {"MFMA16x16x32", "MFMA32x32x16", "v_fma_f32", "v_exp_f32", "MFMA16x16x32 (+6 fma each)", "v_pk_fma_f32", "operand-split pairs (4 instr + 2 adds each)",
-                            "ds_read_b128 (1 KB each)", "global_load_dwordx4 from L2 (1 KB each)", "global_load_dwordx4 from HBM (1 KB each)"};
+    const char *what[12] = {"MFMA16x16x32", "MFMA32x32x16", "v_fma_f32", "v_exp_f32", "MFMA16x16x32 (+6 fma each)", "v_pk_fma_f32", "operand-split pairs (4 instr + 2 adds each)",
+                            "ds_read_b128 (1 KB each)", "global_load_dwordx4 from L2 (1 KB each)", "global_load_dwordx4 from HBM (1 KB each)",
+                            "MFMA_i32_16x16x64_i8", "MFMA_i32_32x32x32_i8"};
     printf("mode %d: %.3e %s wave-instructions/s over %.1f s (%.2f per SIMD per us)", mode, rate, what[mode], el, rate / 1024 / 1e6);
-    if (mode >= 7) printf("  = %.2f TB/s", rate * 1024 / 1e12);
+    if (mode >= 7 && mode <= 9) printf("  = %.2f TB/s", rate * 1024 / 1e12);
     printf("\n");
     return 0;
 }
