@@ -29,78 +29,83 @@
 namespace balf {
 namespace {
 // ------------------------------------------------------------------------------------------------
-// GEMM: acc[NT0 .. NT0+NTC)[P] += W[rows of weight tiles wnt0.. , K range kt0..kt0+ktn) * in
-//   wf    : fragment-ordered weights (layout.h), KTtot = K/16 tiles per weight row-tile
+// GEMM: acc[0 .. NTT)[P] += W[weight row tiles wnt0 .. wnt0 + NTT, K tiles kt0 .. kt0 + KTN) * in
+//   w     : fragment-ordered weights (layout.h), KTtot = K/16 tiles per weight row-tile
 //   bload : (kk, p) -> f4 holding input channels 16*(kt0'+kk) + 4*q + {0..3} of pixel tile p
-// The kt loop is a runtime loop; the next step's weight fragments are prefetched into registers.
+// The output row tiles are processed in chunks of CH (bounds the live weight fragments); the whole sequence of
+// steps (chunk, kk) is ONE software pipeline, unrolled at compile time, with the weight fragments of step v + D - 1 requested
+// before the MFMAs of step v: a step is CH * P * 4 MFMAs of 32 cycles -- 512 cycles at C >= 128 -- and a fragment comes from L2
+// in ~700 (a tenth of them from beyond L2), so the one-step lookahead of rounds 1-4 (D = 2) left every step waiting
+// (matrix pipe 0.57-0.65 busy in every stage, profiles/r5_pmc.json).  Accumulation order per output is unchanged
+// (kk ascending, then the four K-slots): results are bit-identical for every D.
+// B fragments come from the wave's LDS slot (short latency: DB = 2 steps in flight) or from global memory (DB = D).
 // ------------------------------------------------------------------------------------------------
-template <int NTT, int NT0, int NTC, int P, typename BL>
-__device__ __forceinline__ void gemm_chunk(f4 (&acc)[NTT][P], const f4 *__restrict__ wf, int wnt0, int KTtot,
-                                           int kt0, int ktn, int lane, BL bload) {
-    // uniform byte pointer of weight tile (wnt0 + NT0, kt0) + a 32-bit per-lane offset: lets the compiler
+#ifndef BALF_F32_D32
+#define BALF_F32_D32 2
+#endif
+#ifndef BALF_F32_D64
+#define BALF_F32_D64 2
+#endif
+#ifndef BALF_F32_D128
+#define BALF_F32_D128 2
+#endif
+#ifndef BALF_F32_D256
+#define BALF_F32_D256 4
+#endif
+template <int C> constexpr int gemm_depth() {
+    return C == 32 ? BALF_F32_D32 : C == 64 ? BALF_F32_D64 : C == 128 ? BALF_F32_D128 : BALF_F32_D256;
+}
+
+template <int NTT, int P, int KTN, int D, bool BGLOBAL, typename BL>
+__device__ __forceinline__ void gemm(f4 (&acc)[NTT][P], const float *w, int wnt0, int KTtot, int kt0, int lane, BL bload) {
+    constexpr int CH = (P >= 4) ? 2 : 4;
+    constexpr int NCH = (NTT + CH - 1) / CH, STEPS = NCH * KTN;
+    constexpr int DB = BGLOBAL ? D : 2;
+    static_assert(D >= 2 && DB <= D, "ring depths");
+    // uniform byte pointer of weight tile (wnt0, kt0) + a 32-bit per-lane offset: lets the compiler
     // use the SGPR-base form of global_load (no 64-bit VALU address arithmetic per load)
-    const char *wbase = reinterpret_cast<const char *>(wf + ((size_t)(wnt0 + NT0) * KTtot + kt0) * 64);
+    const char *wbase = reinterpret_cast<const char *>(reinterpret_cast<const f4 *>(w) + ((size_t)wnt0 * KTtot + kt0) * 64);
     const unsigned lane_off = (unsigned)lane * 16u;
     const unsigned nstride = (unsigned)KTtot * 1024u;          // bytes between weight row-tiles
-    auto wload = [&](int nt, int kk) {
-        return *reinterpret_cast<const f4 *>(wbase + ((unsigned)nt * nstride + (unsigned)kk * 1024u) + lane_off);
+    f4 a[D][CH], b[DB][P];
+    auto ntc = [](int c) { return (NTT - c * CH) < CH ? (NTT - c * CH) : CH; };
+    auto load_a = [&](int v) {
+        const int c = v / KTN, kk = v % KTN;
+#pragma unroll
+        for (int nt = 0; nt < CH; ++nt)
+            if (nt < ntc(c))
+                a[v % D][nt] = *reinterpret_cast<const f4 *>(wbase + ((unsigned)(c * CH + nt) * nstride + (unsigned)kk * 1024u) + lane_off);
     };
-    auto compute = [&](const f4 (&a)[NTC], const f4 (&b)[P]) {
+    auto load_b = [&](int v) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) b[v % DB][p] = bload(v % KTN, p);
+    };
+#pragma unroll
+    for (int v = 0; v < D - 1; ++v) if (v < STEPS) load_a(v);
+#pragma unroll
+    for (int v = 0; v < DB - 1; ++v) if (v < STEPS) load_b(v);
+#pragma unroll
+    for (int v = 0; v < STEPS; ++v) {
+        if (v + D - 1 < STEPS) load_a(v + D - 1);
+        if (v + DB - 1 < STEPS) load_b(v + DB - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int c = v / KTN;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int nt = 0; nt < NTC; ++nt)
+            for (int nt = 0; nt < CH; ++nt)
+                if (nt < ntc(c))
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[NT0 + nt][p] = mfma4(a[nt][j], b[p][j], acc[NT0 + nt][p]);
-    };
-    // two register stages (0/1), each loaded one whole compute block ahead of its use; ktn is even
-    f4 a0[NTC], a1[NTC], b0[P], b1[P];
-#pragma unroll
-    for (int nt = 0; nt < NTC; ++nt) a0[nt] = wload(nt, 0);
-#pragma unroll
-    for (int p = 0; p < P; ++p) b0[p] = bload(0, p);
-    for (int kk = 0; kk < ktn; kk += 2) {
-#pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) a1[nt] = wload(nt, kk + 1);
-#pragma unroll
-        for (int p = 0; p < P; ++p) b1[p] = bload(kk + 1, p);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        const int k2 = (kk + 2 < ktn) ? kk + 2 : kk;           // last pass re-loads (harmless, uniform)
-#pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) a0[nt] = wload(nt, k2);
-#pragma unroll
-        for (int p = 0; p < P; ++p) b0[p] = bload(k2, p);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a1, b1);
+                    for (int p = 0; p < P; ++p) acc[c * CH + nt][p] = mfma4(a[v % D][nt][j], b[v % DB][p][j], acc[c * CH + nt][p]);
         __builtin_amdgcn_sched_barrier(0);
     }
-}
-
-template <int NTT, int NT0, int CH, int P, typename BL>
-__device__ __forceinline__ void gemm_from(f4 (&acc)[NTT][P], const f4 *__restrict__ wf, int wnt0, int KTtot, int kt0,
-                                          int ktn, int lane, BL bload) {
-    if constexpr (NT0 < NTT) {
-        constexpr int NTC = (NTT - NT0) < CH ? (NTT - NT0) : CH;
-        gemm_chunk<NTT, NT0, NTC, P>(acc, wf, wnt0, KTtot, kt0, ktn, lane, bload);
-        gemm_from<NTT, NT0 + NTC, CH, P>(acc, wf, wnt0, KTtot, kt0, ktn, lane, bload);
-    }
-}
-
-// all NTT output tiles, in chunks of CH weight row-tiles (bounds the live weight fragments)
-template <int NTT, int P, typename BL>
-__device__ __forceinline__ void gemm(f4 (&acc)[NTT][P], const float *w, int wnt0, int KTtot, int kt0, int ktn,
-                                     int lane, BL bload) {
-    constexpr int CH = (P >= 4) ? 2 : ((P == 2 || NTT <= 16) ? 4 : 8);
-    gemm_from<NTT, 0, CH, P>(acc, reinterpret_cast<const f4 *>(w), wnt0, KTtot, kt0, ktn, lane, bload);
 }
 
 template <int C, int CIN, int MODE>
 __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(StageArgs A) {
     constexpr bool PK = (MODE == 0) && (C == 32);      // packed VALU math only where it measured faster
     constexpr int P = StageP<C>::P;
-    constexpr int NT = C / 16;
+    constexpr int NT = C / 16, GD = gemm_depth<C>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f4 *smem = reinterpret_cast<f4 *>(smem_raw);
     float *bT = reinterpret_cast<float *>(smem_raw);
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(Stage
         }
     } else {
         init_bias(x0, blob + S.conv0_b, q);
-        gemm<NT, P>(x0, blob + S.conv0_w, 0, CIN / 16, 0, CIN / 16, lane,
+        gemm<NT, P, CIN / 16, GD, true>(x0, blob + S.conv0_w, 0, CIN / 16, 0, lane,
                     [&](int kk, int p) { return ldg4(A.X + pix[p] * CIN + 16 * kk + 4 * q); });
         relu(x0);
     }
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(Stage
     auto from_slot = [&](int kk, int p) { return slot[(kk * P + p) * 64 + lane]; };
     f4 z[NT][P];
     init_bias(z, blob + S.q1_b + MODE * C, q);
-    gemm<NT, P>(z, blob + S.q1_w, MODE * NT, NT, 0, NT, lane, from_slot);
+    gemm<NT, P, NT, GD, false>(z, blob + S.q1_w, MODE * NT, NT, 0, lane, from_slot);
     gelu<PK>(z);
 
     // ---- gMLP branch on z ----
@@ -177,12 +182,12 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(Stage
     }
     f4 ga[NT][P];                                      // gate input a = first C outputs of dense1
     init_bias(ga, blob + Br.d1_b, q);
-    gemm<NT, P>(ga, blob + Br.d1_w, 0, NT, 0, NT, lane, from_slot);
+    gemm<NT, P, NT, GD, false>(ga, blob + Br.d1_w, 0, NT, 0, lane, from_slot);
     gelu<PK>(ga);
     {
         f4 gb[NT][P];                                  // b = last C outputs, normalised, then token-mixed
         init_bias(gb, blob + Br.d1_b + C, q);
-        gemm<NT, P>(gb, blob + Br.d1_w, NT, NT, 0, NT, lane, from_slot);
+        gemm<NT, P, NT, GD, false>(gb, blob + Br.d1_w, NT, NT, 0, lane, from_slot);
         gelu<PK>(gb);
         layernorm<PK>(gb, gb, blob + Br.gln_g, blob + Br.gln_b, q);
         __syncthreads();                               // every wave is done reading its slot
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(Stage
     store_slot(slot, ga, lane);
     f4 o[NT][P];
     init_bias(o, blob + Br.d2_b, q);
-    gemm<NT, P>(o, blob + Br.d2_w, 0, NT, 0, NT, lane, from_slot);
+    gemm<NT, P, NT, GD, false>(o, blob + Br.d2_w, 0, NT, 0, lane, from_slot);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -241,8 +246,8 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(Stage
         store_slot(slot, o, lane);                     // v'
         f4 x1[NT][P];
         init_bias(x1, blob + S.q2_b, q);
-        gemm<NT, P>(x1, blob + S.q2_w, 0, 2 * NT, NT, NT, lane, from_slot);
-        gemm<NT, P>(x1, blob + S.q2_w, 0, 2 * NT, 0, NT, lane,
+        gemm<NT, P, NT, GD, false>(x1, blob + S.q2_w, 0, 2 * NT, NT, lane, from_slot);
+        gemm<NT, P, NT, GD, true>(x1, blob + S.q2_w, 0, 2 * NT, 0, lane,
                     [&](int kk, int p) { return ldg4(A.U + pix[p] * C + 16 * kk + 4 * q); });
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -256,12 +261,12 @@ __global__ __launch_bounds__(256, StageP<C>::OCC) void stage_branch_kernel(Stage
         store_slot(slot, x1, lane);
         f4 m1[NT][P];
         init_bias(m1, blob + S.r1_b, q);
-        gemm<NT, P>(m1, blob + S.r1_w, 0, NT, 0, NT, lane, from_slot);
+        gemm<NT, P, NT, GD, false>(m1, blob + S.r1_w, 0, NT, 0, lane, from_slot);
         lrelu(m1);
         store_slot(slot, m1, lane);
         f4 t[NT][P];
         init_bias(t, blob + S.r2_b, q);
-        gemm<NT, P>(t, blob + S.r2_w, 0, NT, 0, NT, lane, from_slot);
+        gemm<NT, P, NT, GD, false>(t, blob + S.r2_w, 0, NT, 0, lane, from_slot);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f4 s = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
 
     f4 f[NT][1];
     init_bias(f, blob + A.off.conv2_b, q);
-    gemm<NT, 1>(f, blob + A.off.conv2_w, 0, NT, 0, NT, lane, [&](int kk, int) {
+    gemm<NT, 1, NT, gemm_depth<256>(), true>(f, blob + A.off.conv2_w, 0, NT, 0, lane, [&](int kk, int) {
         const int c = 16 * kk + 4 * q;
         return ldg4(A.T + pixel * C + c) * ldg4(A.scale + (long)n * C + c) + ldg4(A.R + pixel * C + c);
     });
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
     store_slot(slot, f, lane);
     f4 z[HT][1];
     init_bias(z, blob + A.head_b, q);
-    gemm<HT, 1>(z, blob + A.head_w, 0, NT, 0, NT, lane, [&](int kk, int) { return slot[kk * 64 + lane]; });
+    gemm<HT, 1, NT, gemm_depth<256>(), false>(z, blob + A.head_w, 0, NT, 0, lane, [&](int kk, int) { return slot[kk * 64 + lane]; });
 
     float mx = -INFINITY;
 #pragma unroll
@@ -383,25 +388,48 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
     }
 }
 
+#include "stage1_f32.h"
+
+#ifndef BALF_F32_S1_GENERIC
+#define BALF_F32_S1_GENERIC 0     // 1: stage 1 on the generic kernel (rounds 1-4), for A/B timing
+#endif
+
+template <typename K>
+bool allow_lds32(K k, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+}
+
 template <int C, int CIN>
 int run_stage(int *status, const float *blob, int s, const float *X, const InputU8 &u8, int B, int H, int W, float *U, float *T, float *R,
               float *partial, float *chunk, float *scale, hipStream_t st) {
-    constexpr int P = StageP<C>::P;
-    constexpr int lds = stage_lds_bytes<C, P>();
     StageArgs a{blob, kLayout.st[s], X, u8.p, u8.ch, u8.h, u8.w, u8.top, u8.left, B, H, W, U, T, R, partial};
-    const int per_img = (H / 8) * (W / 8 / P);
-    const int nwg = B * per_img;
-    auto k0 = stage_branch_kernel<C, CIN, 0>;
-    auto k1 = stage_branch_kernel<C, CIN, 1>;
-    if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-                hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-                hipSuccess)
-            return BALF_ERR_LAUNCH;
+    int per_img;                                         // rows of partial channel sums per image
+    if constexpr (C == 32 && !BALF_F32_S1_GENERIC) {
+        // persistent wave-owns-group kernels (stage1_f32.h): one workgroup per CU at most, a multiple of 8 (XCD-aware schedule)
+        per_img = (H / 8) * (W / 8);
+        const long groups = (long)B * per_img;
+        long wgs = (groups + kF1NW - 1) / kF1NW;
+        wgs = (wgs + 7) / 8 * 8;
+        if (wgs > 256) wgs = 256;
+        if (!allow_lds32(stage1_kernel32<0>, f1_lds_bytes<0>()) || !allow_lds32(stage1_kernel32<1>, f1_lds_bytes<1>())) return BALF_ERR_LAUNCH;
+        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(stage1_kernel32<0>, dim3((unsigned)wgs), dim3(kF1NW * 64), f1_lds_bytes<0>(), st, a));
+#if BALF_F32_DBG
+        if (getenv("BALF_DEBUG_STOP_STAGE")) return BALF_OK;
+#endif
+        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(stage1_kernel32<1>, dim3((unsigned)wgs), dim3(kF1NW * 64), f1_lds_bytes<1>(), st, a));
+    } else {
+        constexpr int P = StageP<C>::P;
+        constexpr int lds = stage_lds_bytes<C, P>();
+        per_img = (H / 8) * (W / 8 / P);
+        const int nwg = B * per_img;
+        auto k0 = stage_branch_kernel<C, CIN, 0>;
+        auto k1 = stage_branch_kernel<C, CIN, 1>;
+        if (lds > 48 * 1024) {
+            if (!allow_lds32(k0, lds) || !allow_lds32(k1, lds)) return BALF_ERR_LAUNCH;
+        }
+        BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(k0, dim3(nwg), dim3(256), lds, st, a));
+        BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(k1, dim3(nwg), dim3(256), lds, st, a));
     }
-    BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(k0, dim3(nwg), dim3(256), lds, st, a));
-    BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(k1, dim3(nwg), dim3(256), lds, st, a));
     BALF_PROF(4 * s + 2, st, {
         hipLaunchKernelGGL(se_reduce_kernel<C>, dim3(B * kSeChunks), dim3(256), 0, st, partial, per_img, chunk);
         hipLaunchKernelGGL(se_kernel<C>, dim3(B), dim3(256), 0, st, blob, kLayout.st[s], chunk,
@@ -443,6 +471,9 @@ int forward_f32(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
         if (u8.ch) u8b.p = u8.p + (size_t)b0 * u8.h * u8.w * u8.ch;
         int rc;
         if ((rc = run_stage<32, 3>(status, blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
+#if BALF_F32_DBG
+        if (getenv("BALF_DEBUG_STOP_STAGE")) return BALF_OK;       // (tools/f32_s1_debug.py: the tap in U must survive)
+#endif
         if ((rc = run_pool<32>(0, T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
         if ((rc = run_stage<64, 32>(status, blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
         if ((rc = run_pool<64>(1, T, R, scale, nb, Hp / 2, Wp / 2, X3, st)) != BALF_OK) return rc;

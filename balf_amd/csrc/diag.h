@@ -41,13 +41,16 @@
 #ifndef BALF_DEBUG_STOP
 #define BALF_DEBUG_STOP 0        // the f16 forward stops after the stage named by the environment variable BALF_DEBUG_STOP_STAGE (tools/s2_debug.py)
 #endif
+#ifndef BALF_F32_DBG
+#define BALF_F32_DBG 0           // exact-fp32 stage-1 grid kernel (stage1_f32.h) stores intermediate tensor k into U; with BALF_DEBUG_STOP_STAGE set the forward stops there (tools/f32_s1_debug.py)
+#endif
 #ifndef BALF_S1_STRICT
 #define BALF_S1_STRICT 0         // every hand-placed vmcnt wait of the persistent kernels drains the queue (debugging aid: correct, slow)
 #endif
 
 #define BALF_DIAGNOSTIC_BUILD                                                                                      \
     (BALF_ABLATE_GELU || BALF_ABLATE_BARRIER || BALF_ABLATE_LOADLAT || BALF_ABLATE_LUTCOPY || BALF_ABLATE_WSTREAM || \
-     BALF_ABLATE_SPLIT || BALF_DROP_WLO || BALF_STAMPS || BALF_HN_STAMPS || BALF_S1_STRICT || BALF_DEBUG_STOP || BALF_ABLATE_QSTREAM)
+     BALF_ABLATE_SPLIT || BALF_DROP_WLO || BALF_STAMPS || BALF_HN_STAMPS || BALF_S1_STRICT || BALF_DEBUG_STOP || BALF_ABLATE_QSTREAM || BALF_F32_DBG)
 #if BALF_DIAGNOSTIC_BUILD && !defined(BALF_ALLOW_DIAGNOSTIC_BUILD)
 #error "a diagnostic switch (csrc/diag.h) is set: pass -DBALF_ALLOW_DIAGNOSTIC_BUILD=1 as well (tools/build_variant.sh does) -- such a library must not ship"
 #endif
@@ -59,4 +62,4 @@
     BALF_DIAG_ITEM(BALF_ABLATE_GELU) BALF_DIAG_ITEM(BALF_ABLATE_BARRIER) BALF_DIAG_ITEM(BALF_ABLATE_LOADLAT)        \
     BALF_DIAG_ITEM(BALF_ABLATE_LUTCOPY) BALF_DIAG_ITEM(BALF_ABLATE_WSTREAM) BALF_DIAG_ITEM(BALF_ABLATE_SPLIT)       \
     BALF_DIAG_ITEM(BALF_DROP_WLO) BALF_DIAG_ITEM(BALF_STAMPS) BALF_DIAG_ITEM(BALF_HN_STAMPS) BALF_DIAG_ITEM(BALF_S1_STRICT) \
-    BALF_DIAG_ITEM(BALF_DEBUG_STOP) BALF_DIAG_ITEM(BALF_ABLATE_QSTREAM)
+    BALF_DIAG_ITEM(BALF_DEBUG_STOP) BALF_DIAG_ITEM(BALF_ABLATE_QSTREAM) BALF_DIAG_ITEM(BALF_F32_DBG)

@@ -274,3 +274,29 @@ def test_the_vmcnt_audit_itself_catches_what_it_is_for():
     no_wait = loop([("s_waitcnt", "vmcnt(2)"), ("global_load_dwordx4", "v[4:7], v20, s[2:3]"), store, store,
                     ("global_load_dwordx4", "v[12:15], v21, s[2:3]"), ("s_waitcnt", "lgkmcnt(0)")])
     assert va.audit(no_wait)[0]
+
+
+def test_fp32_stage1_pair_sums_add_both_results_of_their_lane_swap():
+    """The same mis-fold in the exact-fp32 stage-1 kernels (stage1_f32.h: f1_pair_sum): the LayerNorm statistics add the two
+    results of a v_permlane32_swap; without the opaque pass-through hipcc emitted `v_add_f32 v17, v0, v0` (seen in the
+    assembly, round 5: every LayerNorm of the kernel was wrong).  Every swap (vA, vB) of the built kernels must be consumed by
+    an add that reads both registers."""
+    va = _audit_module()
+    kernels = va.disassemble(_lib.LIB_PATH, r"stage1_kernel32ILi[01]E")
+    assert len(kernels) == 2, list(kernels)
+    for name, ins in kernels.items():
+        swaps = [(i, ops) for i, (_, mn, ops) in enumerate(ins) if mn and mn.startswith("v_permlane32_swap")]
+        assert len(swaps) >= 12, (name, len(swaps))              # two per LayerNorm and tile
+        for i, ops in swaps:
+            a, b = (_regs(o.strip()) for o in ops.split(","))
+            assert a and b and not (a & b), (name, ops)
+            for _, mn, o2 in ins[i + 1:i + 60]:
+                if not mn or not re.match(r"v_add_f32", mn):
+                    continue
+                srcs = [_regs(s.strip()) for s in o2.split(",")[1:3]]
+                if not any((a | b) & s for s in srcs):
+                    continue
+                assert any(a & s for s in srcs) and any(b & s for s in srcs), (name, ops, mn, o2)
+                break
+            else:
+                raise AssertionError(f"{name}: no add consumes the swap {ops}")

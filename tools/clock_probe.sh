@@ -1,15 +1,16 @@
 #!/bin/bash
-# Sample GPU clock / power while the forward runs back to back (development aid): tools/clock_probe.sh [seconds]
+# Sample GPU clock / power while the forward runs back to back (development aid): tools/clock_probe.sh [seconds] [fp16|fp32]
 root="$(cd "$(dirname "$0")/.." && pwd)"
 secs=${1:-8}
-python3 - "$secs" <<'PY' &
+prec=${2:-fp16}
+python3 - "$secs" "$prec" <<'PY' &
 import os, sys, time, torch
 sys.path.insert(0, ".")
 os.environ["BALF_FP16_CHECK"] = "0"      # (a timing-ablation library fails the split-f16 range check and would be run on the fp32 kernels)
 from balf_amd import arch
 from balf_amd.model import get_model
 from balf_amd.utils import synth
-m = get_model.load_model(arch.DEFAULT_MODEL_CFG); m.load_state_dict(synth.synthetic_state_dict(1)); m = m.eval().cuda()
+m = get_model.load_model(arch.DEFAULT_MODEL_CFG); m.load_state_dict(synth.synthetic_state_dict(1)); m.precision = sys.argv[2]; m = m.eval().cuda()
 x = torch.rand((8, 3, 1088, 1920), device="cuda")
 for _ in range(3): m(x, want_logits=False)
 torch.cuda.synchronize()
