@@ -137,7 +137,8 @@ int main(int argc, char **argv) {
     (void)hipMalloc(&out, 256 * 512 * 4);
     const int iters = mode >= 7 ? 4000 : 20000;
     char *buf = nullptr;
-    const unsigned long long span = mode == 9 ? (4ull << 30) : (1ull << 20);
+    const unsigned long long span = argc > 3 ? ((unsigned long long)atoll(argv[3]) << 20)      // (round 5) MB: 64 = Infinity-Cache resident
+                                             : mode == 9 ? (4ull << 30) : (1ull << 20);
     if (mode >= 8) {
         (void)hipMalloc(&buf, span);
         (void)hipMemset(buf, 1, span);
