@@ -34,6 +34,9 @@ def slot_of(kernel: str):
     m = re.match(r"stage1_kernel16<(\d)", k)
     if m:
         return "stage1_pool" if m.group(1) == "2" else "stage1_%s_branch" % ("grid" if m.group(1) == "0" else "block")
+    m = re.match(r"stage1_kernel32<(\d)", k)                            # (exact-fp32 stage 1 since round 5, stage1_f32.h)
+    if m:
+        return "stage1_%s_branch" % ("grid" if m.group(1) == "0" else "block")
     m = re.match(r"stage2_kernel16<(\d)", k)
     if m:
         return "stage2_pool" if m.group(1) == "2" else "stage2_%s_branch" % ("grid" if m.group(1) == "0" else "block")
@@ -86,7 +89,9 @@ for prec in ("fp16", "fp32"):
         if c.get("SQ_WAVE_CYCLES"):
             simd_cycles = 1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0
             # (stages 1-2 of the split-f16 path issue v_mfma_f32_32x32x16_f16: twice the MACs and cycles of a 16x16x32)
-            mf = c.get("SQ_INSTS_MFMA", 0.0) * (2.0 if prec == "fp16" and s.startswith(("stage1_", "stage2_")) and not s.endswith("_se") else 1.0)
+            # (and the fp32 stage-1 kernels v_mfma_f32_32x32x2_f32: 64 cycles against 32 for the 16x16x4)
+            big = s.startswith(("stage1_", "stage2_")) if prec == "fp16" else s in ("stage1_grid_branch", "stage1_block_branch")
+            mf = c.get("SQ_INSTS_MFMA", 0.0) * (2.0 if big and not s.endswith("_se") else 1.0)
             d.update({"waves": c["SQ_WAVES"], "valu_insts": c["SQ_INSTS_VALU"], "mfma_insts": c.get("SQ_INSTS_MFMA", 0.0),
                       "issue_share": (c["SQ_INSTS_VALU"] * 2.6 + mf * mfma_cycles) / simd_cycles,
                       "wave_wait_share": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
