@@ -44,7 +44,13 @@ template <int MODE> constexpr int f1_weight_bytes() { return MODE == 0 ? kF1Q2 :
 enum F1Par { kF1pConv0B = 0, kF1pQ1B = 32, kF1pD1B = 64, kF1pGlnG = 128, kF1pGlnB = 160, kF1pMixB1 = 192, kF1pD2B = 256,
              kF1pQ2B = 288, kF1pR1B = 320, kF1pR2B = 352, kF1ParFloats = 384 };
 constexpr int kF1BtBytes = kF1C * 256;                             // transposed token tile of a wave: 32 channel rows x 64 tokens
-template <int MODE> constexpr int f1_lds_bytes() { return f1_weight_bytes<MODE>() + kF1ParFloats * 4 + kF1NW * kF1BtBytes; }
+// ... then the GELU chord table of the split-f16 kernels (layout.h: kGeluLutN intervals over [-6, 6), weights.hip builds it; chord
+// error 7.6e-7 against 8.6e-7 for the 2^P polynomial of the generic kernel), then the token tiles.  fp32 MFMAs and vector
+// instructions share one pipe (see above), so a vector instruction saved is time saved: 4 + 1 LDS read per value instead of 8.
+constexpr int kF1LutBytes = ((kGeluLutN + 1) * 8 + 15) / 16 * 16;
+template <int MODE> constexpr int f1_lut_offset() { return f1_weight_bytes<MODE>() + kF1ParFloats * 4; }
+template <int MODE> constexpr int f1_lds_bytes() { return f1_lut_offset<MODE>() + kF1LutBytes + kF1NW * kF1BtBytes; }
+static_assert(f1_lut_offset<1>() < 0x10000, "the table's base must fit the 16-bit offset field of ds_read (the index is the address register)");
 static_assert(f1_lds_bytes<1>() <= 160 * 1024, "stage-1 fp32 LDS image");
 
 // float index of W[n][k] inside an A-fragment-ordered [N, K] matrix of the blob (layout.h, weights.hip: pack_frags)
@@ -111,21 +117,68 @@ __device__ __forceinline__ void f1_linear(f16v (&acc)[2], const unsigned char *w
             for (int p = 0; p < 2; ++p) acc[p] = mfma32f(a[g][e], b[p][4 * g + e], acc[p]);
 }
 
-// accumulator start value: the bias of the lane's 16 channels (8 g + 4 h + r), the same for both tiles
-__device__ __forceinline__ void f1_bias(f16v (&t)[2], const float *par, int h) {
+// the bias of the lane's 16 channels (8 g + 4 h + r), four LDS reads: the C operand of a Linear's FIRST MFMA of both tiles
+// (an MFMA's C and D may be different registers: no v_mov per accumulator register -- 32 vector instructions per Linear)
+__device__ __forceinline__ f16v f1_bias_vec(const float *par, int h) {
+    f16v t;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f4 b = *reinterpret_cast<const f4 *>(par + 8 * g + 4 * h);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { t[0][4 * g + r] = b[r]; t[1][4 * g + r] = b[r]; }
+        for (int r = 0; r < 4; ++r) t[4 * g + r] = b[r];
     }
+    return t;
 }
 
+// acc[p] = bias + W . b[p]
+__device__ __forceinline__ void f1_linear_b(f16v (&acc)[2], const unsigned char *wl, const f16v (&b)[2], const float *bias, int h) {
+    f4 a[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) a[g] = *reinterpret_cast<const f4 *>(wl + g * 1024);
+    const f16v bv = f1_bias_vec(bias, h);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) acc[p] = mfma32f(a[0][0], b[p][0], bv);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (g + e)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) acc[p] = mfma32f(a[g][e], b[p][4 * g + e], acc[p]);
+}
+
+// exact (erf) GELU from the chord table: y = clamp01(x / 12 + 1/2), t = 8 N y + 1.5 * 2^23 (the rounded 8 N y lands in the low
+// mantissa bits), (a, b) = table[bits(t) & 0x7FF8], gelu = a + b x  (stage1_f16.h: gelu_lut_off; the table's LDS offset is a
+// constant, it goes into the read's offset field)
+#ifndef BALF_F32_PREFETCH
+#define BALF_F32_PREFETCH 1
+#endif
+#ifndef BALF_F32_GELU_LUT
+#define BALF_F32_GELU_LUT 1
+#endif
+template <int LUT_OFF>
 __device__ __forceinline__ void f1_gelu(f16v (&t)[2]) {
+    // (raw LDS addresses: the dynamic LDS block of these kernels starts at LDS address 0 -- they have no static __shared__ --, so
+    // masked bits + a constant ARE the address and the constant goes into the read's offset field; through a generic pointer hipcc
+    // spends a v_add_u32 per read on adding the LDS symbol's zero.  The last fma is asm with the result in x's own register: left
+    // to itself hipcc pairs two of them into a v_pk_fma_f32 behind three v_mov_b32 -- both seen in this kernel's first build, both
+    // as in stage1_f16.h: gelu_lut_pipe)
+    typedef const f2 __attribute__((address_space(3))) *lds_f2_ptr;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t[p][r] = gelu1<false>(t[p][r]);
+        for (int r = 0; r < 16; ++r) {
+            float x = t[p][r];
+            if (BALF_F32_GELU_LUT) {
+                const float y = __builtin_amdgcn_fmed3f(fmaf(x, 0.5f / kGeluLutL, 0.5f), 0.0f, 1.0f);
+                const float u = fmaf(y, 8.0f * kGeluLutN, 12582912.0f);
+                const f2 ab = *reinterpret_cast<lds_f2_ptr>((__builtin_bit_cast(unsigned, u) & 0x7FF8u) + (unsigned)LUT_OFF);
+                asm("v_fma_f32 %0, %1, %0, %2" : "+v"(x) : "v"(ab[1]), "v"(ab[0]));
+                t[p][r] = x;
+            } else {
+                t[p][r] = gelu1<false>(x);
+            }
+        }
 }
 
 // BALF_F32_DBG = k (diag.h; tools/f32_s1_debug.py): the grid kernel stores intermediate tensor k into U instead of u'
@@ -176,6 +229,11 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
                 d[i] = blob[Br.mix_w + f1_frag_index(2 * (ln & 31) + pt, 8 * j + 4 * (ln >> 5) + e, kTokens)];
             }
         }
+        if (BALF_F32_GELU_LUT) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(blob + kLayout.gelu_lut);
+            for (int i = threadIdx.x; i < kF1LutBytes / 16; i += NTHR)
+                reinterpret_cast<uint4 *>(smem_raw + f1_lut_offset<MODE>())[i] = src[i];
+        }
         // conv0 [32, 3] as A operands of two MFMAs (K = 3 padded to 4): lane (m, h) holds W[m][h] and W[m][2] (h = 0) / 0 (h = 1)
         for (int i = threadIdx.x; i < 64; i += NTHR) {
             const int m = i & 31, hh = i >> 5;
@@ -199,7 +257,7 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
         __syncthreads();                                         // the only barrier of the kernel
     }
 
-    unsigned char *bT = smem_raw + f1_weight_bytes<MODE>() + kF1ParFloats * 4 + wave * kF1BtBytes;
+    unsigned char *bT = smem_raw + f1_lut_offset<MODE>() + kF1LutBytes + wave * kF1BtBytes;
     const unsigned char *wl = smem_raw + lane * 16;
     const float2 a0 = *reinterpret_cast<const float2 *>(smem_raw + kF1Conv0 + lane * 8);
 
@@ -214,68 +272,93 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
     const int ty = n >> 2, tx0 = 2 * (n & 3);
     const int pstep = (MODE == 0) ? fw : 1;
 
-    for (int item = xcd * nx + wx; item < total; item += stride) {
-        const int img = item / per_img;
-        const int rem = item - img * per_img;
+    // a group's lane geometry and its raw input (conv0's B operands: bx[p] = input channel h, bx[2 + p] = channel 2 of pixel tile p)
+    struct Geo { int img, y, x0; long pix0; };
+    auto geo = [&](int item) {
+        Geo g;
+        g.img = item / per_img;
+        const int rem = item - g.img * per_img;
         const int gy = rem / fw, gx = rem - gy * fw;
-        int y, x0;
-        if (MODE == 0) { y = ty * fh + gy; x0 = tx0 * fw + gx; }
-        else           { y = 8 * gy + ty;  x0 = 8 * gx + tx0; }
-        const long pix0 = ((long)img * H + y) * W + x0;
-
-        // ---- x0 = relu(conv0(X)) on the matrix pipe ----
-        float bx[4];
+        if (MODE == 0) { g.y = ty * fh + gy; g.x0 = tx0 * fw + gx; }
+        else           { g.y = 8 * gy + ty;  g.x0 = 8 * gx + tx0; }
+        g.pix0 = ((long)g.img * H + g.y) * W + g.x0;
+        return g;
+    };
+    auto load_bx = [&](const Geo &g, float (&bx)[4]) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             float in3[3];
-            load_input3(A, blob + kLayout.u8_lut, img, y, x0 + p * pstep, in3);
+            load_input3(A, blob + kLayout.u8_lut, g.img, g.y, g.x0 + p * pstep, in3);
             bx[p] = h ? in3[1] : in3[0];
             bx[2 + p] = in3[2];
         }
+    };
+    // The loads of a group are requested long before their use (BALF_F32_PREFETCH; with the loads at their use 12 % of the
+    // kernels' time was exposed latency, profiles/r5_f32.txt): the NEXT group's input pixels right after this group's conv0, the u'
+    // rows (block branch) behind the token mix, where the gate's registers have died -- each pinned by a scheduling fence, the waits
+    // are the compiler's own counted ones.
+    float nbx[4] = {};
+    int item = xcd * nx + wx;
+    if (BALF_F32_PREFETCH && item < total) load_bx(geo(item), nbx);
+    for (; item < total; item += stride) {
+        const Geo gg_ = geo(item);
+        const int img = gg_.img, y = gg_.y, x0 = gg_.x0;
+        const long pix0 = gg_.pix0;
+        (void)img; (void)y; (void)x0;
+
+        // ---- x0 = relu(conv0(X)) on the matrix pipe ----
+        float bx[4];
+        if (!BALF_F32_PREFETCH) load_bx(gg_, nbx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bx[i] = nbx[i];
         f16v ub[(MODE == 1) ? 2 : 1];                            // block: u' rows of the lane's pixels (NHWC fp32)
-        if constexpr (MODE == 1) {
+        auto load_u = [&]() {
+            if constexpr (MODE == 1) {
 #pragma unroll
-            for (int p = 0; p < P; ++p)
+                for (int p = 0; p < P; ++p)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f4 v = ldg4(A.U + (pix0 + p * pstep) * C + 8 * g + 4 * h);
+                    for (int g = 0; g < 4; ++g) {
+                        const f4 v = ldg4(A.U + (pix0 + p * pstep) * C + 8 * g + 4 * h);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ub[p][4 * g + r] = v[r];
-                }
-        }
+                        for (int r = 0; r < 4; ++r) ub[p][4 * g + r] = v[r];
+                    }
+            }
+        };
+        if (!BALF_F32_PREFETCH) load_u();
         f16v x0v[2];
-        f1_bias(x0v, par + kF1pConv0B, h);
+        const f16v c0b = f1_bias_vec(par + kF1pConv0B, h);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            x0v[p] = mfma32f(a0.x, bx[p], x0v[p]);
+            x0v[p] = mfma32f(a0.x, bx[p], c0b);
             x0v[p] = mfma32f(a0.y, bx[2 + p], x0v[p]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) x0v[p][r] = max0(x0v[p][r]);
         }
 
+        if (BALF_F32_PREFETCH) {
+            load_bx(geo(item + stride < total ? item + stride : item), nbx);     // (the last group re-requests its own pixels)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         F1_DBG(1, x0v)
         // ---- z = GELU(dense1[MODE half](LN(x0))) : u (grid) or v (block) ----
         f16v hb[2];
         f1_ln_plain(x0v, hb);
         F1_DBG(2, hb)
         f16v z[2];
-        f1_bias(z, par + kF1pQ1B, h);
-        f1_linear(z, wl + kF1Q1, hb);
-        f1_gelu(z);
+        f1_linear_b(z, wl + kF1Q1, hb, par + kF1pQ1B, h);
+        f1_gelu<f1_lut_offset<MODE>()>(z);
         F1_DBG(3, z)
 
         // ---- gMLP branch on z ----
         f1_ln_plain(z, hb);
         f16v ga[2];
-        f1_bias(ga, par + kF1pD1B, h);
-        f1_linear(ga, wl + kF1D1, hb);
-        f1_gelu(ga);
+        f1_linear_b(ga, wl + kF1D1, hb, par + kF1pD1B, h);
+        f1_gelu<f1_lut_offset<MODE>()>(ga);
         F1_DBG(4, ga)
         {
             f16v gb[2];
-            f1_bias(gb, par + kF1pD1B + C, h);
-            f1_linear(gb, wl + kF1D1 + 4096, hb);
-            f1_gelu(gb);
+            f1_linear_b(gb, wl + kF1D1 + 4096, hb, par + kF1pD1B + C, h);
+            f1_gelu<f1_lut_offset<MODE>()>(gb);
             // gating LayerNorm (affine) -> transposed token tile bT[c][t], t = 2 n + p: 8-byte stores, the row's sixteen
             // 16-byte chunks XOR-swizzled by the row so that the 16-byte A-operand reads below spread over the banks
             float rstd[P], shift[P];
@@ -288,8 +371,9 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int c = 8 * g + 4 * h + r;
-                    const float v0 = fmaf(fmaf(gb[0][4 * g + r], rstd[0], shift[0]), gg[r], bb[r]);
-                    const float v1 = fmaf(fmaf(gb[1][4 * g + r], rstd[1], shift[1]), gg[r], bb[r]);
+                    float v0 = fmaf(fmaf(gb[0][4 * g + r], rstd[0], shift[0]), gg[r], bb[r]);
+                    float v1 = fmaf(fmaf(gb[1][4 * g + r], rstd[1], shift[1]), gg[r], bb[r]);
+                    asm("" : "+v"(v0), "+v"(v1));      // (opaque: hipcc otherwise pairs the two tiles' fmas into v_pk_fma_f32 behind three v_mov_b32)
                     *reinterpret_cast<float2 *>(bT + c * 256 + (((n >> 1) ^ (c & 15)) << 4) + (n & 1) * 8) = make_float2(v0, v1);
                 }
             }
@@ -316,10 +400,13 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
                 for (int r = 0; r < 16; ++r) ga[pt][r] *= m[r];
             }
         }
+        if (BALF_F32_PREFETCH) {
+            load_u();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         F1_DBG(5, ga)
         f16v o[2];
-        f1_bias(o, par + kF1pD2B, h);
-        f1_linear(o, wl + kF1D2, ga);
+        f1_linear_b(o, wl + kF1D2, ga, par + kF1pD2B, h);
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
@@ -335,8 +422,7 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
         } else {
             // ---- x1 = dense2(cat[u', v']) + x0 ----
             f16v x1[2];
-            f1_bias(x1, par + kF1pQ2B, h);
-            f1_linear(x1, wl + kF1Q2 + 4096, o);                 // v' half
+            f1_linear_b(x1, wl + kF1Q2 + 4096, o, par + kF1pQ2B, h);      // v' half
             f1_linear(x1, wl + kF1Q2, ub);                       // u' half
 #pragma unroll
             for (int p = 0; p < P; ++p) {
@@ -351,15 +437,13 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
             // ---- t = conv2(lrelu(conv1(LN(x1)))) ----
             f1_ln_plain(x1, hb);
             f16v m1[2];
-            f1_bias(m1, par + kF1pR1B, h);
-            f1_linear(m1, wl + kF1R1, hb);
+            f1_linear_b(m1, wl + kF1R1, hb, par + kF1pR1B, h);
 #pragma unroll
             for (int p = 0; p < P; ++p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m1[p][r] = __builtin_fmaxf(m1[p][r], 0.2f * m1[p][r]);
             f16v t[2];
-            f1_bias(t, par + kF1pR2B, h);
-            f1_linear(t, wl + kF1R2, m1);
+            f1_linear_b(t, wl + kF1R2, m1, par + kF1pR2B, h);
 #pragma unroll
             for (int p = 0; p < P; ++p)
 #pragma unroll
