@@ -150,9 +150,6 @@ __device__ __forceinline__ void f1_linear_b(f16v (&acc)[2], const unsigned char 
 // exact (erf) GELU from the chord table: y = clamp01(x / 12 + 1/2), t = 8 N y + 1.5 * 2^23 (the rounded 8 N y lands in the low
 // mantissa bits), (a, b) = table[bits(t) & 0x7FF8], gelu = a + b x  (stage1_f16.h: gelu_lut_off; the table's LDS offset is a
 // constant, it goes into the read's offset field)
-#ifndef BALF_F32_PREFETCH
-#define BALF_F32_PREFETCH 1
-#endif
 #ifndef BALF_F32_GELU_LUT
 #define BALF_F32_GELU_LUT 1
 #endif
@@ -293,25 +290,17 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
             bx[2 + p] = in3[2];
         }
     };
-    // The loads of a group are requested long before their use (BALF_F32_PREFETCH; with the loads at their use 12 % of the
-    // kernels' time was exposed latency, profiles/r5_f32.txt): the NEXT group's input pixels right after this group's conv0, the u'
-    // rows (block branch) behind the token mix, where the gate's registers have died -- each pinned by a scheduling fence, the waits
-    // are the compiler's own counted ones.
-    float nbx[4] = {};
-    int item = xcd * nx + wx;
-    if (BALF_F32_PREFETCH && item < total) load_bx(geo(item), nbx);
-    for (; item < total; item += stride) {
+    for (int item = xcd * nx + wx; item < total; item += stride) {
         const Geo gg_ = geo(item);
-        const int img = gg_.img, y = gg_.y, x0 = gg_.x0;
         const long pix0 = gg_.pix0;
-        (void)img; (void)y; (void)x0;
 
         // ---- x0 = relu(conv0(X)) on the matrix pipe ----
         float bx[4];
-        if (!BALF_F32_PREFETCH) load_bx(gg_, nbx);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bx[i] = nbx[i];
-        f16v ub[(MODE == 1) ? 2 : 1];                            // block: u' rows of the lane's pixels (NHWC fp32)
+        load_bx(gg_, bx);
+        // (block) the u' rows of the lane's pixels (NHWC fp32) are requested behind the token mix, where the gate's registers have
+        // died, pinned there by a scheduling fence (the compiler otherwise sinks them to their use); requesting the next group's
+        // pixels a group ahead as well measured nothing (profiles/r5_f32.txt)
+        f16v ub[(MODE == 1) ? 2 : 1];
         auto load_u = [&]() {
             if constexpr (MODE == 1) {
 #pragma unroll
@@ -324,7 +313,6 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
                     }
             }
         };
-        if (!BALF_F32_PREFETCH) load_u();
         f16v x0v[2];
         const f16v c0b = f1_bias_vec(par + kF1pConv0B, h);
 #pragma unroll
@@ -335,10 +323,6 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
             for (int r = 0; r < 16; ++r) x0v[p][r] = max0(x0v[p][r]);
         }
 
-        if (BALF_F32_PREFETCH) {
-            load_bx(geo(item + stride < total ? item + stride : item), nbx);     // (the last group re-requests its own pixels)
-            __builtin_amdgcn_sched_barrier(0);
-        }
         F1_DBG(1, x0v)
         // ---- z = GELU(dense1[MODE half](LN(x0))) : u (grid) or v (block) ----
         f16v hb[2];
@@ -400,10 +384,8 @@ __global__ __launch_bounds__(kF1NW * 64, 1) void stage1_kernel32(StageArgs A) {
                 for (int r = 0; r < 16; ++r) ga[pt][r] *= m[r];
             }
         }
-        if (BALF_F32_PREFETCH) {
-            load_u();
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        load_u();
+        __builtin_amdgcn_sched_barrier(0);
         F1_DBG(5, ga)
         f16v o[2];
         f1_linear_b(o, wl + kF1D2, ga, par + kF1pD2B, h);
