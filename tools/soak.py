@@ -1,5 +1,5 @@
-"""Determinism soak of the f16 forward: N repetitions at full load, every result must be bit-identical to the first.
-Usage: python tools/soak.py [reps] [batch] [H] [W]"""
+"""Determinism soak of the forward: N repetitions at full load, every result must be bit-identical to the first.
+Usage: python tools/soak.py [reps] [batch] [H] [W] [fp16|fp32]"""
 import sys, torch
 sys.path.insert(0, ".")
 from balf_amd import arch
@@ -9,7 +9,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 b = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 1088
 w = int(sys.argv[4]) if len(sys.argv) > 4 else 1920
-m = get_model.load_model(arch.DEFAULT_MODEL_CFG); m.load_state_dict(synth.synthetic_state_dict(7)); m.precision = "fp16"; m = m.eval().cuda()
+m = get_model.load_model(arch.DEFAULT_MODEL_CFG); m.load_state_dict(synth.synthetic_state_dict(7)); m.precision = sys.argv[5] if len(sys.argv) > 5 else "fp16"; m = m.eval().cuda()
 x = torch.rand((b, 3, h, w), device="cuda")
 with torch.inference_mode():
     ref = m(x)
@@ -24,4 +24,4 @@ with torch.inference_mode():
             w = d.nonzero()
             print("mismatch at repetition", i, int(d.sum()), "differing score-map values; max abs diff %.3e" % float((o["prob"] - ref["prob"]).abs().max()),
                   "first at (image, y, x)", w[0].tolist() if len(w) else None, "last", w[-1].tolist() if len(w) else None, flush=True)
-print(f"{reps} repetitions of {b}x{h}x{w}: {bad} mismatches, finite={bool(torch.isfinite(ref['prob']).all())}")
+print(f"{m.effective_precision}: {reps} repetitions of {b}x{h}x{w}: {bad} mismatches, finite={bool(torch.isfinite(ref['prob']).all())}")
