@@ -24,6 +24,8 @@
 //   se_kernel        per image: mean(t) -> C/4 -> C MLP -> sigmoid                (deterministic order)
 //   pool_kernel      stages 1-3: x2 = t*s + r, 2x2 max pool -> next stage's NHWC input
 //   head_kernel      stage 4: x2 -> conv2 -> relu -> dense(256->65) -> BN -> softmax -> pixel shuffle
+#include <atomic>
+
 #include "det_common.h"
 
 namespace balf {
@@ -394,9 +396,18 @@ __global__ __launch_bounds__(256, 2) void head_kernel(HeadArgs A) {
 #define BALF_F32_S1_GENERIC 0     // 1: stage 1 on the generic kernel (rounds 1-4), for A/B timing
 #endif
 
-template <typename K>
-bool allow_lds32(K k, int bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+// hipFuncSetAttribute is a driver round trip (tens of microseconds): once per kernel and device of the process, not per launch
+// (as ensure_kernel_attributes of detector_f16.hip; a single-image call on the fp32 path made four of them)
+template <auto Kernel>
+bool allow_lds32(int bytes) {
+    static std::atomic<unsigned long long> done{0};              // bit d: device d has the attribute
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (done.load(std::memory_order_acquire) >> dev & 1) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return false;
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return true;
 }
 
 template <int C, int CIN>
@@ -411,7 +422,7 @@ int run_stage(int *status, const float *blob, int s, const float *X, const Input
         long wgs = (groups + kF1NW - 1) / kF1NW;
         wgs = (wgs + 7) / 8 * 8;
         if (wgs > 256) wgs = 256;
-        if (!allow_lds32(stage1_kernel32<0>, f1_lds_bytes<0>()) || !allow_lds32(stage1_kernel32<1>, f1_lds_bytes<1>())) return BALF_ERR_LAUNCH;
+        if (!allow_lds32<stage1_kernel32<0>>(f1_lds_bytes<0>()) || !allow_lds32<stage1_kernel32<1>>(f1_lds_bytes<1>())) return BALF_ERR_LAUNCH;
         BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(stage1_kernel32<0>, dim3((unsigned)wgs), dim3(kF1NW * 64), f1_lds_bytes<0>(), st, a));
 #if BALF_F32_DBG
         if (getenv("BALF_DEBUG_STOP_STAGE")) return BALF_OK;
@@ -425,7 +436,7 @@ int run_stage(int *status, const float *blob, int s, const float *X, const Input
         auto k0 = stage_branch_kernel<C, CIN, 0>;
         auto k1 = stage_branch_kernel<C, CIN, 1>;
         if (lds > 48 * 1024) {
-            if (!allow_lds32(k0, lds) || !allow_lds32(k1, lds)) return BALF_ERR_LAUNCH;
+            if (!allow_lds32<stage_branch_kernel<C, CIN, 0>>(lds) || !allow_lds32<stage_branch_kernel<C, CIN, 1>>(lds)) return BALF_ERR_LAUNCH;
         }
         BALF_PROF(4 * s + 0, st, hipLaunchKernelGGL(k0, dim3(nwg), dim3(256), lds, st, a));
         BALF_PROF(4 * s + 1, st, hipLaunchKernelGGL(k1, dim3(nwg), dim3(256), lds, st, a));
