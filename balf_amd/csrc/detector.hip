@@ -483,7 +483,7 @@ int forward_f32(const float *blob, const float *x_nchw_dev, const InputU8 &u8, i
         int rc;
         if ((rc = run_stage<32, 3>(status, blob, 0, x, u8b, nb, Hp, Wp, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;
 #if BALF_F32_DBG
-        if (getenv("BALF_DEBUG_STOP_STAGE")) return BALF_OK;       // (tools/f32_s1_debug.py: the tap in U must survive)
+        if (getenv("BALF_DEBUG_STOP_STAGE")) return BALF_OK;       // (tests/experiments/f32_s1_debug.py: the tap in U must survive)
 #endif
         if ((rc = run_pool<32>(0, T, R, scale, nb, Hp, Wp, X2, st)) != BALF_OK) return rc;
         if ((rc = run_stage<64, 32>(status, blob, 1, X2, InputU8{nullptr, 0, 0, 0, 0, 0}, nb, Hp / 2, Wp / 2, U, T, R, partial, chunk, scale, st)) != BALF_OK) return rc;

@@ -39,10 +39,10 @@
 #define BALF_ABLATE_QSTREAM 0    // stage-2 block kernel: RSHMAG.dense2's weights are read from LDS (another Linear's tiles) instead of streamed from L2
 #endif
 #ifndef BALF_DEBUG_STOP
-#define BALF_DEBUG_STOP 0        // the f16 forward stops after the stage named by the environment variable BALF_DEBUG_STOP_STAGE (tools/s2_debug.py)
+#define BALF_DEBUG_STOP 0        // the f16 forward stops after the stage named by the environment variable BALF_DEBUG_STOP_STAGE (tests/experiments/s2_debug.py)
 #endif
 #ifndef BALF_F32_DBG
-#define BALF_F32_DBG 0           // exact-fp32 stage-1 grid kernel (stage1_f32.h) stores intermediate tensor k into U; with BALF_DEBUG_STOP_STAGE set the forward stops there (tools/f32_s1_debug.py)
+#define BALF_F32_DBG 0           // exact-fp32 stage-1 grid kernel (stage1_f32.h) stores intermediate tensor k into U; with BALF_DEBUG_STOP_STAGE set the forward stops there (tests/experiments/f32_s1_debug.py)
 #endif
 #ifndef BALF_S1_STRICT
 #define BALF_S1_STRICT 0         // every hand-placed vmcnt wait of the persistent kernels drains the queue (debugging aid: correct, slow)

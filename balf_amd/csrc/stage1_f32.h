@@ -178,7 +178,7 @@ __device__ __forceinline__ void f1_gelu(f16v (&t)[2]) {
         }
 }
 
-// BALF_F32_DBG = k (diag.h; tools/f32_s1_debug.py): the grid kernel stores intermediate tensor k into U instead of u'
+// BALF_F32_DBG = k (diag.h; tests/experiments/f32_s1_debug.py): the grid kernel stores intermediate tensor k into U instead of u'
 #define F1_DBG(K, TENSOR)                                                                                       \
     if (BALF_F32_DBG == K && MODE == 0) {                                                                       \
         _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_)       \

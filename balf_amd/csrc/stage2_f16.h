@@ -661,7 +661,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
                 for (int r = 0; r < 8; ++r) {
                     // (plain float temporaries: __builtin_bit_cast applied to a vector ELEMENT, bit_cast(unsigned, m1[rt][r]), reads
                     // the vector's first element whatever r is -- clang takes the object representation at the vector's address.
-                    // Found by tools/s2_debug.py as SE scales off by 0.4: every channel sum was that of register 0.)
+                    // Found by tests/experiments/s2_debug.py as SE scales off by 0.4: every channel sum was that of register 0.)
                     const float ea = m1[rt][r], eb = m1[rt][r + 8];
                     const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ea), __builtin_bit_cast(unsigned, eb), false, false);
                     unsigned w0 = sw[0], w1 = sw[1];             // (opaque: hipcc once folded sw[1] into sw[0] here, see stage1_f16.h)

@@ -1,4 +1,4 @@
-"""Debugging aid for the fp32 stage-1 kernels (stage1_f32.h).
+"""Debugging aid for the fp32 stage-1 kernels (stage1_f32.h); test infrastructure: the tap mode drives the oracle.
   dump out.npy | cmp a.npy b.npy : stage-1 output (stage view) of the exact-fp32 forward for one library build / two dumps compared
   tap K : with a library built with -DBALF_F32_DBG=K (tools/build_variant.sh) and BALF_DEBUG_STOP_STAGE=1: the grid kernel's
           intermediate tensor K (1 x0, 2 LN(x0), 3 u, 4 gate input a, 5 gated a) against torch on the CPU"""
@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def setup():

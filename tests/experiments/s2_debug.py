@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from balf_amd import _lib, arch, ops                                   # noqa: E402
 from balf_amd.model import get_model                                   # noqa: E402
 from balf_amd.utils import synth                                       # noqa: E402
