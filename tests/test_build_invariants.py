@@ -301,3 +301,14 @@ def test_fp32_stage1_pair_sums_add_both_results_of_their_lane_swap():
                 break
             else:
                 raise AssertionError(f"{name}: no add consumes the swap {ops}")
+
+
+def test_fp32_kernels_do_not_spill(tmp_path):
+    """The exact-fp32 kernels sit at their register targets (252 of 256 at C = 128, 442 of 512 at C = 256 with four weight steps in
+    flight): the GEMM's ring depth (detector.hip: BALF_F32_D*) was chosen per stage so that none of them spills -- D = 3 at C = 128
+    did (5 registers, 4 % slower, profiles/r5_f32.txt)."""
+    meta = _kernel_metadata(tmp_path)
+    names = [n for n in meta if "stage_branch_kernel" in n or ("head_kernel" in n and "16" not in n) or "stage1_kernel32" in n]
+    assert len(names) >= 6 + 1 + 2, names                  # generic kernel: stages 2-4 x 2 modes; head; stage 1 x 2 modes
+    for n in names:
+        assert meta[n]["vgpr_spill_count"] == 0 and meta[n]["private_segment_fixed_size"] == 0, (n, meta[n])
