@@ -5,7 +5,6 @@ Training (``train_model``, losses, optimiser; train_utils.py:20-160) is out of s
 * ``compute_repeatability_with_maximum_filter`` (train_utils.py:170-196): window-max NMS of both score maps, common-
   region masks (supplied by the caller: the reference builds them with ``cv2.warpPerspective``, which is not rebuilt
   here), top-K points, homography of the destination points, repeatability.
-* ``ckpt_state`` (train_utils.py:198-202): the checkpoint dict ``get_model.load_*`` reads back.
 """
 from __future__ import annotations
 
@@ -27,8 +26,3 @@ def compute_repeatability_with_maximum_filter(src_scores_np, dst_scores_np, homo
     return ([r['rep_single_scale']], [r['rep_multi_scale']], [r['error_overlap_single_scale']],
             [r['error_overlap_multi_scale']], [r['possible_matches']])
 
-
-def ckpt_state(model=None, optimizer=None, epoch=None, rep_s=0.):
-    optim_state = optimizer.state_dict() if optimizer is not None else optimizer
-    model_state = model.state_dict() if model is not None else None
-    return {'epoch': epoch, 'model_state': model_state, 'optimizer_state': optim_state, 'repeatability': rep_s}
