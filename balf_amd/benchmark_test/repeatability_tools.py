@@ -51,6 +51,8 @@ def compute_repeatability(src_indexes, dst_indexes, overlap_err=0.4, eps=1e-6, d
                                            current_stream_ptr(dev)), "balf_repeatability")
         c = counts.cpu().numpy()
         e = errors.cpu().numpy()
+        if c[0] < 0 or c[1] < 0:            # the candidate list of a scale did not fit max_edges (reported by the device)
+            raise BalfHipError(f"balf_repeatability: more than {cap} candidate pairs (BALF_ERR_WORKSPACE)")
         found = [int(c[0]), int(c[1])]
         possible = int(c[2])
         errs = [float(e[0]), float(e[1])]

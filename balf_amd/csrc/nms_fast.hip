@@ -11,10 +11,28 @@
 // Priority = (score, then raster-first) packed into one 64-bit key, so the result is deterministic; the
 // reference's order among exactly equal scores is whatever NumPy's unstable argsort produces.
 //
-// Kernels: greedy_init (crop + border + threshold -> key map), greedy_keep (LDS-tiled separable window max of
-// the 64-bit keys), greedy_kill (window OR of the newly-kept flags, alive count per tile; newly kept points are
-// appended to the survivor list here), then the top-K / sort kernel of nms_topk.hip and the optional sub-pixel
-// soft-argmax.  Tiles without alive candidates are skipped by both passes, so the long tail of rounds is cheap.
+// Round-6 form: STREAM-ORDERED (no hipStreamSynchronize, no read-back) with one bit per pixel of state.
+//   * state in HBM: an `alive` bit map and a `kept in this round` bit map ([B][H][ceil(W/64)] 64-bit words), per 64 x 32
+//     tile the round after which it holds no candidate (`dead_round`), per image two ping-pong lists of the tiles that
+//     still hold candidates.  The score map is read-only; the 64-bit keys exist in LDS only.
+//   * a round = two launches over each image's list of live tiles:
+//       keep -- tile + d halo of keys in LDS, separable (2d+1)^2 window maximum with one v_max_f64 per comparison (a key is
+//               a positive normal double: (score bits + 2^20) << 32 | ~index orders exactly like the unsigned integer);
+//               where the halo region holds <= 512 candidates (every round but the first on a real score map) a pairwise
+//               test of the enumerated candidates instead.  Round 1 takes its candidates straight from the score map
+//               (crop, border, threshold in the load) and writes the alive map.
+//       kill -- window OR of the kept bits as shifts of one 128-bit row word, alive &= ~that, kept points appended to the
+//               survivor list, the tile to the next round's list (or dead_round = round).
+//     A neighbour tile that was already dead when the round began is never read (dead_round < round): its words are stale.
+//   * the number of rounds is data dependent (4-8 on score maps, ~W/d on a monotone ramp).  `rounds_launched` rounds are
+//     always enqueued; a launch whose image list is empty returns at once.  What is still alive after them is finished by
+//     greedy_tail_kernel: ONE workgroup per image looping rounds over its own list until the list is empty -- images are
+//     independent, so no workgroup ever waits for another one and every wave reaches its exit.
+// Then the top-K / sort kernel of nms_topk.hip and the optional sub-pixel soft-argmax.
+#include <stdlib.h>
+
+#include <atomic>
+
 #include "common.h"
 #include "prof.h"
 
@@ -25,175 +43,547 @@ int balf_topk_select_launch(const int2 *surv, const int *counts, long cap, int B
 namespace {
 
 typedef unsigned long long u64;
-constexpr int GT = 32;            // tile side
-constexpr int GD_MAX = 16;        // max dist_thresh
-constexpr int GTHREADS = 256;
+typedef unsigned __int128 u128;
+constexpr int TW = 64, TH = 32;              // tile: one 64-bit word wide
+constexpr int GD_MAX = 16;                   // max dist_thresh (<= TH, <= TW: a halo reaches the adjacent tiles only)
+constexpr int KTHREADS = 256;                // keep kernel, tail kernel
+constexpr int LTHREADS = 64;                 // kill kernel: one wave per tile
+constexpr int RS = TW + 2 * GD_MAX + 1;      // LDS row stride in keys: 97 = 194 dwords = 2 mod 64 -> a column of keys is conflict-free
+constexpr int RH_MAX = TH + 2 * GD_MAX;      // 64 region rows
+constexpr int NS = 512;                      // pairwise mode up to this many candidates in the halo region
+constexpr int ROUNDS_DEFAULT = 16;           // rounds enqueued as launches of their own before the per-image tail
+constexpr unsigned KEY_BIAS = 0x00100000u;   // keeps a key's high word out of the double's denormal range
+constexpr int ALIVE_FOREVER = 0x7f7f7f7f;    // dead_round of a tile with candidates (hipMemsetAsync 0x7f)
 
 struct GreedyArgs {
     const float *src;             // [B, Hs, Ws]
     int Hs, Ws, crop_y, crop_x, H, W, border;
     float conf;
     int d;                        // dist_thresh
-    u64 *key;                     // [B, H, W]  (score bits << 32 | ~idx) while alive, 0 otherwise
-    unsigned *newk;               // [B, H, ceil(W/32)] bit map: kept in the current round
-    int2 *surv;                   // [B, cap] kept points (flat index, score bits), appended as they are kept
-    int *counts;                  // [B]
-    int *alive;                   // [1] alive candidates left (written by the last round of a group)
-    int count_alive;
-    const int *tile_in;           // [B, tiles]  alive candidates per 32x32 tile before this round
-    int *tile_out;                // [B, tiles]  ... after it (written by the kill pass)
+    int B, ntx, nty;              // tiles per row / column; 64-bit words per bit-map row = ntx
+    u64 *alive;                   // [B, H, ntx]
+    u64 *kept;                    // [B, H, ntx] kept in the current round
+    int *dead_round;              // [B, nty * ntx]
+    int *list;                    // [2, B, nty * ntx] live tiles: list[r & 1] is read by round r, written by round r - 1
+    int *dlist;                   // [B, nty * ntx] live tiles of the current round with > NS candidates around them (window mode)
+    int *ctr;                     // counters, one per 256-byte line (CTR_STRIDE ints): survivors [B], list lengths [2, B], dlist length [B]
+    int2 *surv;                   // [B, H * W] kept points (flat index, score bits), appended as they are kept
+    int *counts;                  // [B] survivors per image, contiguous (written by the tail kernel for the top-K kernel)
 };
+// every counter is hit by one atomic per tile and round: each gets a cache line (and so an L2 channel) of its own -- with
+// the 32 images' counters in one 128-byte line the first kill pass spent 0.4 ms queueing on that line
+constexpr int CTR_STRIDE = 64;
+__device__ __forceinline__ int *ctr_surv(const GreedyArgs &a, int b) { return a.ctr + (long)b * CTR_STRIDE; }
+__device__ __forceinline__ int *ctr_list(const GreedyArgs &a, int parity, int b) { return a.ctr + ((long)(1 + parity) * a.B + b) * CTR_STRIDE; }
+__device__ __forceinline__ int *ctr_dlist(const GreedyArgs &a, int b) { return a.ctr + ((long)3 * a.B + b) * CTR_STRIDE; }
 
 __device__ __forceinline__ float g_score(const GreedyArgs &a, const float *img, int y, int x) {
     if (y < a.border || y >= a.H - a.border || x < a.border || x >= a.W - a.border) return 0.0f;
     return img[(long)(a.crop_y + y) * a.Ws + (a.crop_x + x)];
 }
 
-__global__ __launch_bounds__(GTHREADS) void greedy_init_kernel(GreedyArgs a) {
-    const long hw = (long)a.H * a.W;
-    const int b = blockIdx.y;
-    const float *img = a.src + (long)b * a.Hs * a.Ws;
-    for (long i = (long)blockIdx.x * GTHREADS + threadIdx.x; i < hw; i += (long)gridDim.x * GTHREADS) {
-        const int y = (int)(i / a.W), x = (int)(i - (long)y * a.W);
-        const float v = g_score(a, img, y, x);
-        a.key[b * hw + i] = (v >= a.conf) ? (((u64)__float_as_uint(v) << 32) | (u64)(0xffffffffu - (unsigned)i)) : 0ull;
-    }
+__device__ __forceinline__ double make_key(float v, int idx) {
+    const u64 k = ((u64)(__float_as_uint(v) + KEY_BIAS) << 32) | (u64)(0xffffffffu - (unsigned)idx);
+    return __longlong_as_double((long long)k);
+}
+// maximum of two keys (positive normal doubles or +0) = the unsigned maximum of their bit patterns, in one instruction
+__device__ __forceinline__ double kmax(double x, double y) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
 }
 
-__device__ __forceinline__ u64 umax64(u64 x, u64 y) { return x > y ? x : y; }
+// workgroup barrier that waits for the LDS traffic only: the score values requested for the next tile stay in flight
+// (__syncthreads() drains vmcnt too).  One asm statement with a memory clobber, so nothing moves across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Window maxima of R consecutive outputs that share most of their inputs: out[j] = max(in[j .. j+w-1]), j = 0..R-1.
 // The w-R+1 inputs common to all R windows are reduced once; each output adds a running maximum from the left
 // remainder and one from the right remainder: ~(w + 3R) max operations for R outputs instead of R (w - 1).
-// Keys are unsigned and 0 means "dead", so 0 is the identity.
+// +0 means "dead" and is the identity.
 template <int R, typename In, typename Out>
 __device__ __forceinline__ void window_max_run(int w, In in, Out out) {
     if (w >= R) {
-        u64 core = in(R - 1);
-        for (int k = R; k < w; ++k) core = umax64(core, in(k));
-        u64 left[R], right[R];
-        u64 acc = 0ull;
-        left[R - 1] = 0ull;
+        // the reads of a batch are independent (issued together, one wait): with two waves per SIMD a read-max-read chain
+        // of 30 LDS round trips per item was the whole kernel
+        double left[R], right[R], t[8];
 #pragma unroll
-        for (int j = R - 2; j >= 0; --j) { acc = umax64(acc, in(j)); left[j] = acc; }
-        acc = 0ull;
-        right[0] = 0ull;
+        for (int j = 0; j < R - 1; ++j) left[j] = in(j);
 #pragma unroll
-        for (int j = 1; j < R; ++j) { acc = umax64(acc, in(w - 1 + j)); right[j] = acc; }
+        for (int j = 1; j < R; ++j) right[j] = in(w - 1 + j);
+        double core = in(R - 1);
+        int k = R;
+        for (; k + 8 <= w; k += 8) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) out(j, umax64(core, umax64(left[j], right[j])));
+            for (int u = 0; u < 8; ++u) t[u] = in(k + u);
+            core = kmax(core, kmax(kmax(kmax(t[0], t[1]), kmax(t[2], t[3])), kmax(kmax(t[4], t[5]), kmax(t[6], t[7]))));
+        }
+        for (; k < w; ++k) core = kmax(core, in(k));
+        double acc = 0.0;
+#pragma unroll
+        for (int j = R - 2; j >= 0; --j) { acc = kmax(acc, left[j]); left[j] = acc; }
+        left[R - 1] = 0.0;
+        acc = 0.0;
+#pragma unroll
+        for (int j = 1; j < R; ++j) { acc = kmax(acc, right[j]); right[j] = acc; }
+        right[0] = 0.0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) out(j, kmax(core, kmax(left[j], right[j])));
     } else {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            u64 m = in(j);
-            for (int k = 1; k < w; ++k) m = umax64(m, in(j + k));
+            double m = in(j);
+            for (int k = 1; k < w; ++k) m = kmax(m, in(j + k));
             out(j, m);
         }
     }
 }
 
-// newk is a bit map: word [b][y][tx] holds the "kept in this round" flags of pixels x = 32 tx .. 32 tx + 31 of row y
-__global__ __launch_bounds__(GTHREADS) void greedy_keep_kernel(GreedyArgs a) {
-    constexpr int S = GT + 2 * GD_MAX;
-    __shared__ u64 s_in[S * (S + 1)];
-    __shared__ u64 s_row[S * (GT + 1)];
-    const int d = a.d, side = GT + 2 * d, w = 2 * d + 1;
-    const int b = blockIdx.z, ty0 = blockIdx.y * GT, tx0 = blockIdx.x * GT;
-    const long hw = (long)a.H * a.W;
-    const u64 *key = a.key + b * hw;
-    unsigned *bits = a.newk + ((long)b * a.H) * gridDim.x + blockIdx.x;       // + y * gridDim.x
-    // a tile without alive candidates keeps nobody: after the first rounds that is almost every tile, and the long
-    // tail of rounds (a dozen on real score maps) costs a few bytes per tile instead of a window max
-    if (a.tile_in[((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] == 0) {
-        if (threadIdx.x < GT && ty0 + threadIdx.x < a.H) bits[(long)(ty0 + threadIdx.x) * gridDim.x] = 0u;
-        return;
+struct KeepLds {
+    double in[RH_MAX * RS];        // region keys (window mode); the candidate keys of the pairwise mode alias it
+    double col[TH * RS];           // vertical window maxima; the candidate positions of the pairwise mode alias it
+    u64 words[RH_MAX * 3];         // alive words of the region rows: left neighbour / own / right neighbour tile column, masked to the region
+    unsigned kbits[TH * 2];        // kept bits of the tile's rows
+    unsigned abits[TH * 2];        // alive bits of the tile's rows (round 1)
+    int n, m, pad_[2];
+};
+struct KillLds {
+    u64 h[RH_MAX];                 // per region row: horizontal window OR of the kept bits, bit c = tile column c
+    int dead[12];                  // the 3 x 3 tile neighbourhood: dead when the round began
+};
+struct SparseLds {                 // pairwise keep pass, one wave per tile
+    double key[NS];
+    int2 pos[NS];
+    u64 words[RH_MAX * 3];
+    unsigned kbits[TH * 2];
+    int dead[12];
+    int n, m;
+};
+
+// did the tile (tyi, txi) of image b hold no candidate when `round` began?  (tiles outside the image: yes)
+__device__ __forceinline__ bool tile_dead(const GreedyArgs &a, int b, int tyi, int txi, int round) {
+    if (tyi < 0 || tyi >= a.nty || txi < 0 || txi >= a.ntx) return true;
+    return a.dead_round[((long)b * a.nty + tyi) * a.ntx + txi] < round;
+}
+
+// The two window passes over the keys in s.in (tile + d halo) and the kept / alive bits of the tile's rows into s.kbits /
+// s.abits (zeroed by the caller before the barrier this begins with).
+template <bool FIRST>
+__device__ __forceinline__ void window_passes(const GreedyArgs &a, KeepLds &s, int tyi, int txi) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int d = a.d, w = 2 * d + 1, RW = TW + 2 * d;
+    lds_barrier();
+    for (int i = tid; i < RW * (TH / 8); i += nthr) {                      // column pass: 8 outputs per item, lanes along x
+        const int blk = i / RW, c = i - blk * RW, r0 = blk * 8;
+        const double *col = s.in + r0 * RS + c;
+        window_max_run<8>(w, [&](int k) { return col[k * RS]; }, [&](int j, double v) { s.col[(r0 + j) * RS + c] = v; });
     }
-    for (int i = threadIdx.x; i < side * side; i += GTHREADS) {
-        const int r = i / side, c = i - r * side;
-        const int y = ty0 - d + r, x = tx0 - d + c;
-        s_in[r * (S + 1) + c] = (y >= 0 && y < a.H && x >= 0 && x < a.W) ? key[(long)y * a.W + x] : 0ull;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < side * (GT / 8); i += GTHREADS) {        // row pass: 8 outputs per item
-        const int r = i / (GT / 8), c0 = (i - r * (GT / 8)) * 8;
-        const u64 *row = s_in + r * (S + 1) + c0;
-        window_max_run<8>(w, [&](int k) { return row[k]; }, [&](int j, u64 v) { s_row[r * (GT + 1) + c0 + j] = v; });
-    }
-    __syncthreads();
-    {                                                                       // column pass: 4 outputs per item
-        const int c = threadIdx.x & (GT - 1), r0 = (threadIdx.x >> 5) * 4;  // 32 columns x 8 row groups of 4
-        const u64 *col = s_row + r0 * (GT + 1) + c;
-        unsigned keep4 = 0;
-        window_max_run<4>(w, [&](int k) { return col[k * (GT + 1)]; }, [&](int j, u64 m) {
-            const u64 own = s_in[(r0 + j + d) * (S + 1) + c + d];
-            if (own != 0ull && own == m) keep4 |= 1u << j;
+    lds_barrier();
+    for (int i = tid; i < TH * (TW / 8); i += nthr) {                      // row pass: 8 outputs per item, lanes along y
+        const int r = i & (TH - 1), blk = i / TH, c0 = blk * 8;
+        const double *row = s.col + r * RS + c0;
+        unsigned keep8 = 0, alive8 = 0;
+        window_max_run<8>(w, [&](int k) { return row[k]; }, [&](int j, double m) {
+            const double own = s.in[(r + d) * RS + c0 + j + d];
+            if (own != 0.0) {
+                alive8 |= 1u << j;
+                if (own == m) keep8 |= 1u << j;
+            }
         });
-        // one word per row: bit c of row r0 + j = lane's flag j; the 32 lanes of a row group sit in one half wave
+        if (keep8) atomicOr(&s.kbits[r * 2 + (blk >> 2)], keep8 << ((blk & 3) * 8));
+        if (FIRST && alive8) atomicOr(&s.abits[r * 2 + (blk >> 2)], alive8 << ((blk & 3) * 8));
+    }
+}
+
+// Keep pass of one tile in rounds >= 2 (window-mode kernel and tail): writes the tile's words of the `kept` map.  All
+// threads of the workgroup take part (blockDim.x a multiple of 64).
+__device__ void keep_tile(const GreedyArgs &a, KeepLds &s, int b, int tile, int round) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const int d = a.d, RH = TH + 2 * d, RW = TW + 2 * d;
+    const int ry0 = ty0 - d, rx0 = tx0 - d;
+    const float *img = a.src + (long)b * a.Hs * a.Ws;
+    __syncthreads();                                  // the workgroup's previous tile is done with the LDS
+    if (tid < TH * 2) s.kbits[tid] = 0u;
+    if (tid == 0) { s.n = 0; s.m = 0; }
+    bool window_mode;
+    {
+        for (int i = tid; i < RH * 3; i += nthr) {
+            const int r = i / 3, j = i - r * 3, y = ry0 + r, wx = txi - 1 + j;
+            u64 v = 0ull;
+            if (y >= 0 && y < a.H && !tile_dead(a, b, y / TH, wx, round)) {
+                v = a.alive[((long)b * a.H + y) * a.ntx + wx];
+                if (j == 0) v = d ? (v >> (64 - d)) << (64 - d) : 0ull;         // columns tx0-d .. tx0-1
+                if (j == 2) v = d ? (v & ((1ull << d) - 1ull)) : 0ull;          // columns tx0+64 .. tx0+63+d
+            }
+            s.words[i] = v;
+        }
+        __syncthreads();
+        int c = 0;
+        for (int i = tid; i < RH * 3; i += nthr) c += __popcll(s.words[i]);
+        if (c) atomicAdd(&s.n, c);
+        __syncthreads();
+        window_mode = s.n > NS;
+    }
+    if (window_mode) {
+        for (int i = tid; i < RH * RW; i += nthr) {
+            const int r = i / RW, c = i - r * RW;
+            const int bit = c + 64 - d;                                         // bit 0 of word 0 = column tx0 - 64
+            double k = 0.0;
+            if ((s.words[r * 3 + (bit >> 6)] >> (bit & 63)) & 1ull) k = make_key(g_score(a, img, ry0 + r, rx0 + c), (ry0 + r) * a.W + rx0 + c);
+            s.in[r * RS + c] = k;
+        }
+        window_passes<false>(a, s, tyi, txi);
+    } else {
+        // pairwise mode: enumerate the region's candidates (position, key); a candidate of the tile is kept iff no
+        // candidate with a higher key lies within Chebyshev distance d -- all of those are inside the region
+        int2 *ex = reinterpret_cast<int2 *>(s.col);
+        double *ek = s.in;
+        for (int i = tid; i < RH * 3; i += nthr) {
+            u64 v = s.words[i];
+            if (!v) continue;
+            const int r = i / 3, j = i - r * 3, y = ry0 + r;
+            int e = atomicAdd(&s.m, __popcll(v));
+            while (v) {
+                const int bit = __builtin_ctzll(v);
+                v &= v - 1ull;
+                const int x = tx0 + (j - 1) * 64 + bit;
+                ex[e] = make_int2(x, y);
+                ek[e] = make_key(g_score(a, img, y, x), y * a.W + x);
+                ++e;
+            }
+        }
+        __syncthreads();
+        const int n = s.n;
+        for (int e = tid; e < n; e += nthr) {
+            const int2 p = ex[e];
+            if (p.x < tx0 || p.x >= tx0 + TW || p.y < ty0 || p.y >= ty0 + TH) continue;
+            const double k = ek[e];
+            bool keep = true;
+            for (int q = 0; q < n; ++q) {
+                const int2 o = ex[q];
+                if (ek[q] > k && abs(o.x - p.x) <= d && abs(o.y - p.y) <= d) { keep = false; break; }
+            }
+            if (keep) atomicOr(&s.kbits[(p.y - ty0) * 2 + ((p.x - tx0) >> 5)], 1u << ((p.x - tx0) & 31));
+        }
+    }
+    __syncthreads();
+    if (tid < TH && ty0 + tid < a.H) {
+        const long wi = ((long)b * a.H + ty0 + tid) * a.ntx + txi;
+        a.kept[wi] = (u64)s.kbits[tid * 2] | ((u64)s.kbits[tid * 2 + 1] << 32);
+    }
+}
+
+// wave-wide helpers (64 lanes, all active)
+__device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned long long bal = __ballot((keep4 >> j) & 1u);
-            const unsigned word = (unsigned)((threadIdx.x & 32) ? (bal >> 32) : bal);
-            const int y = ty0 + r0 + j;
-            if (c == 0 && y < a.H) bits[(long)y * gridDim.x] = word;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Kill pass of one tile.  Wave 0 of the workgroup does the work; every thread must call it (two barriers).
+__device__ void kill_tile(const GreedyArgs &a, KillLds &s, int b, int tile, int round) {
+    const int tid = threadIdx.x;
+    const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const int d = a.d, w = 2 * d + 1, RH = TH + 2 * d;
+    const float *img = a.src + (long)b * a.Hs * a.Ws;
+    // every global load of the pass is issued before anything waits: dead flags, the kept words of the region rows (stale
+    // words of dead tiles are read and masked afterwards), the tile's own alive and kept words
+    u64 L = 0ull, M = 0ull, R = 0ull, al = 0ull, kp = 0ull;
+    int tr = 0;
+    __syncthreads();                                  // the previous tile of this workgroup is done with the LDS
+    if (tid < 64) {
+        if (tid < 9) s.dead[tid] = tile_dead(a, b, tyi - 1 + tid / 3, txi - 1 + tid % 3, round);
+        if (tid < RH) {
+            const int y = ty0 - d + tid;
+            if (y >= 0 && y < a.H) {
+                tr = y / TH - (tyi - 1);
+                const u64 *row = a.kept + ((long)b * a.H + y) * a.ntx;
+                if (txi > 0) L = row[txi - 1];
+                M = row[txi];
+                if (txi + 1 < a.ntx) R = row[txi + 1];
+            }
+        }
+        if (tid < TH && ty0 + tid < a.H) {
+            const long wi = ((long)b * a.H + ty0 + tid) * a.ntx + txi;
+            al = a.alive[wi];
+            kp = a.kept[wi];
+        }
+    }
+    __syncthreads();
+    if (tid < RH) {
+        if (s.dead[tr * 3 + 0]) L = 0ull;
+        if (s.dead[tr * 3 + 1]) M = 0ull;
+        if (s.dead[tr * 3 + 2]) R = 0ull;
+        // 128 bits of the row, bit k = column tx0 - 16 + k
+        u128 t = ((u128)((M >> 48) | (R << 16)) << 64) | (u128)((L >> 48) | (M << 16));
+        int have = 1;                                 // OR over a window of w bits by doubling
+        while (2 * have <= w) { t |= t >> have; have *= 2; }
+        t |= t >> (w - have);                         // bit k = OR of bits k .. k + w - 1
+        s.h[tid] = (u64)(t >> (16 - d));              // bit c = OR of the columns tx0 + c - d .. tx0 + c + d
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    u64 v = 0ull;
+    if (tid < TH)
+        for (int q = 0; q < w; ++q) v |= s.h[tid + q];
+    // newly kept points onto the survivor list: one atomic per tile
+    const int nk = __popcll(kp);
+    const int incl = wave_incl_scan(nk);
+    const int total = __shfl(incl, 63);
+    if (total) {
+        int base = 0;
+        if (tid == 0) base = atomicAdd(ctr_surv(a, b), total);
+        base = __shfl(base, 0);
+        int2 *out = a.surv + (long)b * a.H * a.W + base + incl - nk;
+        const int y = ty0 + tid;
+        while (kp) {
+            const int x = tx0 + __builtin_ctzll(kp);
+            kp &= kp - 1ull;
+            *out++ = make_int2(y * a.W + x, (int)__float_as_uint(g_score(a, img, y, x)));
+        }
+    }
+    const u64 na = al & ~v;                            // the kept ones themselves and whoever they suppress
+    if (na != al) a.alive[((long)b * a.H + ty0 + tid) * a.ntx + txi] = na;
+    const int alive = wave_sum(__popcll(na));
+    if (tid == 0) {
+        if (alive == 0) {
+            a.dead_round[(long)b * a.nty * a.ntx + tile] = round;
+        } else {
+            const int nxt = (round + 1) & 1;
+            const int pos = atomicAdd(ctr_list(a, nxt, b), 1);
+            a.list[((long)nxt * a.B + b) * a.nty * a.ntx + pos] = tile;
         }
     }
 }
 
-__global__ __launch_bounds__(GTHREADS) void greedy_kill_kernel(GreedyArgs a) {
-    constexpr int S = GT + 2 * GD_MAX;
-    __shared__ u64 s_h[S];                          // per halo row: horizontal window-OR of the kept flags
-    __shared__ u64 s_own[S];
-    __shared__ int s_cnt;
-    const int d = a.d, side = GT + 2 * d, w = 2 * d + 1;
-    const int b = blockIdx.z, ty0 = blockIdx.y * GT, tx0 = blockIdx.x * GT;
-    const long hw = (long)a.H * a.W;
-    const long tile = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (a.tile_in[tile] == 0) {                       // nobody alive here: nothing to kill, nothing newly kept
-        if (threadIdx.x == 0) a.tile_out[tile] = 0;
+// Keep pass of rounds >= 2 where the tile's halo region holds <= NS candidates (every tile of a real score map): ONE WAVE
+// per tile and a few KB of LDS, so that a CU keeps dozens of tiles in flight.  Tiles with more candidates go to the
+// window-mode list.  The tile's own candidates are enumerated first (entries 0 .. n_tile - 1): the pairwise loop runs on
+// full lanes.
+__device__ void keep_tile_sparse(const GreedyArgs &a, SparseLds &s, int b, int tile, int round) {
+    const int lane = threadIdx.x;
+    const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const int d = a.d, RH = TH + 2 * d, ry0 = ty0 - d;
+    const float *img = a.src + (long)b * a.Hs * a.Ws;
+    __syncthreads();
+    u64 wv[3] = {0ull, 0ull, 0ull};                   // words lane, lane + 64, lane + 128 of the RH x 3 region words
+    if (lane < 9) s.dead[lane] = tile_dead(a, b, tyi - 1 + lane / 3, txi - 1 + lane % 3, round);
+    if (lane < TH * 2) s.kbits[lane] = 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = lane + 64 * k;
+        if (i < RH * 3) {
+            const int r = i / 3, j = i - r * 3, y = ry0 + r, wx = txi - 1 + j;
+            if (y >= 0 && y < a.H && wx >= 0 && wx < a.ntx) wv[k] = a.alive[((long)b * a.H + y) * a.ntx + wx];
+        }
+    }
+    __syncthreads();
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = lane + 64 * k;
+        if (i < RH * 3) {
+            const int r = i / 3, j = i - r * 3, y = ry0 + r;
+            u64 v = wv[k];
+            if (y < 0 || y >= a.H || s.dead[(y / TH - (tyi - 1)) * 3 + j]) v = 0ull;
+            if (j == 0) v = d ? (v >> (64 - d)) << (64 - d) : 0ull;             // columns tx0-d .. tx0-1
+            if (j == 2) v = d ? (v & ((1ull << d) - 1ull)) : 0ull;              // columns tx0+64 .. tx0+63+d
+            s.words[i] = v;
+            c += __popcll(v);
+        }
+    }
+    __syncthreads();
+    u64 own = lane < TH ? s.words[(lane + d) * 3 + 1] : 0ull;    // the tile's own word of row ty0 + lane
+    const int c_tile = __popcll(own);
+    const int n = wave_sum(c), incl = wave_incl_scan(c_tile), n_tile = __shfl(incl, 63);
+    if (n > NS) {                                      // uniform: too many for the pairwise test
+        if (lane == 0) a.dlist[(long)b * a.nty * a.ntx + atomicAdd(ctr_dlist(a, b), 1)] = tile;
         return;
     }
-    if (threadIdx.x == 0) s_cnt = 0;
-    if (threadIdx.x < side) {
-        // bits x = tx0 - d .. tx0 + 31 + d of halo row r as one 64-bit word (bit k = column tx0 - d + k)
-        const int r = threadIdx.x, y = ty0 - d + r;
-        u64 m = 0ull;
-        if (y >= 0 && y < a.H) {
-            const unsigned *row = a.newk + ((long)b * a.H + y) * gridDim.x;
-            const int tx = blockIdx.x;
-            const u64 mid = row[tx];
-            const u64 lo = tx > 0 ? row[tx - 1] : 0u, hi = tx + 1 < (int)gridDim.x ? row[tx + 1] : 0u;
-            m = (d > 0 ? (lo >> (32 - d)) : 0ull) | (mid << d) | (d > 0 ? (hi << (32 + d)) : 0ull);
+    if (lane == 0) s.m = n_tile;
+    {                                                  // the tile's candidates: entries 0 .. n_tile - 1
+        int e = incl - c_tile;
+        const int y = ty0 + lane;
+        while (own) {
+            s.pos[e++] = make_int2(tx0 + __builtin_ctzll(own), y);
+            own &= own - 1ull;
         }
-        s_own[r] = m;
-        u64 t = m;                                    // horizontal OR over a window of w bits by doubling
-        int have = 1;
-        while (2 * have <= w) { t |= t >> have; have *= 2; }
-        s_h[r] = t | (t >> (w - have));               // bit k = OR of columns k .. k + w - 1
     }
     __syncthreads();
-    int alive = 0;
-    for (int i = threadIdx.x; i < GT * GT; i += GTHREADS) {
-        const int r = i / GT, c = i - r * GT;
-        const int y = ty0 + r, x = tx0 + c;
-        if (y >= a.H || x >= a.W) continue;
-        const long p = b * hw + (long)y * a.W + x;
-        const u64 k = a.key[p];
-        if (k == 0ull) continue;
-        u64 v = 0ull;                                 // vertical OR of the rows r .. r + 2d (wave-uniform per row)
-        for (int q = 0; q < w; ++q) v |= s_h[r + q];
-        if ((s_own[r + d] >> (c + d)) & 1ull) {       // newly kept: straight onto the survivor list
-            const int pos = atomicAdd(&a.counts[b], 1);
-            a.surv[b * hw + pos] = make_int2(y * a.W + x, (int)(k >> 32));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                      // the halo's candidates behind them
+        const int i = lane + 64 * k;
+        if (i < RH * 3) {
+            const int r = i / 3, j = i - r * 3, y = ry0 + r;
+            u64 v = s.words[i];
+            if (j == 1 && r >= d && r < d + TH) v = 0ull;
+            if (v) {
+                int e = atomicAdd(&s.m, __popcll(v));
+                while (v) {
+                    s.pos[e++] = make_int2(tx0 + (j - 1) * 64 + __builtin_ctzll(v), y);
+                    v &= v - 1ull;
+                }
+            }
         }
-        if ((v >> c) & 1ull) a.key[p] = 0ull;         // newly kept itself, or suppressed by a newly kept neighbour
-        else ++alive;
     }
-    if (alive) atomicAdd(&s_cnt, alive);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        a.tile_out[tile] = s_cnt;
-        if (a.count_alive && s_cnt) atomicAdd(a.alive, s_cnt);
+    for (int e = lane; e < n; e += 64) {               // the scores: independent loads, one per lane
+        const int2 p = s.pos[e];
+        s.key[e] = make_key(g_score(a, img, p.y, p.x), p.y * a.W + p.x);
     }
+    __syncthreads();
+    for (int e = lane; e < n_tile; e += 64) {
+        const int2 p = s.pos[e];
+        const double k = s.key[e];
+        bool keep = true;
+        for (int q = 0; q < n; ++q) {
+            const int2 o = s.pos[q];
+            if (s.key[q] > k && abs(o.x - p.x) <= d && abs(o.y - p.y) <= d) { keep = false; break; }
+        }
+        if (keep) atomicOr(&s.kbits[(p.y - ty0) * 2 + ((p.x - tx0) >> 5)], 1u << ((p.x - tx0) & 31));
+    }
+    __syncthreads();
+    if (lane < TH && ty0 + lane < a.H)
+        a.kept[((long)b * a.H + ty0 + lane) * a.ntx + txi] = (u64)s.kbits[lane * 2] | ((u64)s.kbits[lane * 2 + 1] << 32);
+}
+
+// Round 1: every tile, candidates straight from the score map (crop, border, threshold in the load), window mode.
+// PERSISTENT: two workgroups per CU walk contiguous runs of tiles (32 640 short-lived workgroups with 75 KB of LDS each
+// spent a third of the pass being launched), and the next tile's score values are requested into registers before the
+// two window passes of the current one, so that the HBM round trip runs under them (it was half of the pass).
+constexpr int FIRST_WG = 512;
+constexpr int FROWS = RH_MAX / (KTHREADS / 64);          // region rows per wave: 16
+
+// wave wv holds region rows wv, wv + 4, ..., lanes along x (columns lane and lane + 64): coalesced, no index division
+__device__ __forceinline__ void first_fetch(const GreedyArgs &a, int g, float (&v)[FROWS][2]) {
+    const int tiles = a.nty * a.ntx, b = g / tiles, tile = g - b * tiles;
+    const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
+    const int d = a.d, RH = TH + 2 * d, RW = TW + 2 * d, ry0 = tyi * TH - d, rx0 = txi * TW - d;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lo_y = a.border, hi_y = a.H - a.border, lo_x = a.border, hi_x = a.W - a.border;
+    const float *img = a.src + (long)b * a.Hs * a.Ws + (long)a.crop_y * a.Ws + a.crop_x;
+#pragma unroll
+    for (int k = 0; k < FROWS; ++k) {
+        const int r = wv + (KTHREADS / 64) * k, y = ry0 + r;
+        const bool yok = r < RH && y >= lo_y && y < hi_y;
+        const float *rowp = img + (long)y * a.Ws;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = lane + 64 * h, x = rx0 + c;
+            v[k][h] = (yok && c < RW && x >= lo_x && x < hi_x) ? rowp[x] : 0.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(KTHREADS) void greedy_keep_first_kernel(GreedyArgs a, int total, int per) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    KeepLds &s = *reinterpret_cast<KeepLds *>(smem);
+    // consecutive workgroups go to different XCDs (8 L2s): workgroup i takes run (i % 8) * (n / 8) + i / 8, so that each XCD
+    // walks one contiguous eighth of the batch and the halo rows neighbouring tiles share are fetched into one L2 once
+    const int run = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int g0 = run * per, g1 = g0 + per < total ? g0 + per : total;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles = a.nty * a.ntx, d = a.d, RH = TH + 2 * d, RW = TW + 2 * d;
+    float v[FROWS][2];
+    if (g0 < g1) first_fetch(a, g0, v);
+    for (int g = g0; g < g1; ++g) {
+        const int b = g / tiles, tile = g - b * tiles, tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
+        const int ry0 = tyi * TH - d, rx0 = txi * TW - d;
+        lds_barrier();                              // the previous tile is done with the LDS
+        if (tid < TH * 2) { s.kbits[tid] = 0u; s.abits[tid] = 0u; }
+#pragma unroll
+        for (int k = 0; k < FROWS; ++k) {
+            const int r = wv + (KTHREADS / 64) * k;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                if (r < RH && c < RW) s.in[r * RS + c] = v[k][h] >= a.conf ? make_key(v[k][h], (ry0 + r) * a.W + rx0 + c) : 0.0;
+            }
+        }
+        if (g + 1 < g1) first_fetch(a, g + 1, v);     // in flight during the passes
+        window_passes<true>(a, s, tyi, txi);
+        lds_barrier();
+        if (tid < TH && tyi * TH + tid < a.H) {
+            const long wi = ((long)b * a.H + tyi * TH + tid) * a.ntx + txi;
+            a.kept[wi] = (u64)s.kbits[tid * 2] | ((u64)s.kbits[tid * 2 + 1] << 32);
+            a.alive[wi] = (u64)s.abits[tid * 2] | ((u64)s.abits[tid * 2 + 1] << 32);
+        }
+    }
+}
+
+// rounds >= 2, first launch: the listed tiles in pairwise mode; crowded tiles are passed on to greedy_keep_window_kernel
+__global__ __launch_bounds__(LTHREADS) void greedy_keep_sparse_kernel(GreedyArgs a, int round) {
+    __shared__ SparseLds s;
+    const int b = blockIdx.y, tiles = a.nty * a.ntx, cur = round & 1;
+    const int n = *ctr_list(a, cur, b);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ctr_list(a, cur ^ 1, b) = 0;       // this round's kill pass fills it
+    const int *list = a.list + ((long)cur * a.B + b) * tiles;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) keep_tile_sparse(a, s, b, list[i], round);
+}
+
+// rounds >= 2, second launch: the crowded tiles (ramps, plateaus) with the window maximum
+__global__ __launch_bounds__(KTHREADS) void greedy_keep_window_kernel(GreedyArgs a, int round) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    KeepLds &s = *reinterpret_cast<KeepLds *>(smem);
+    const int b = blockIdx.y, tiles = a.nty * a.ntx;
+    const int n = *ctr_dlist(a, b);
+    const int *list = a.dlist + (long)b * tiles;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) keep_tile(a, s, b, list[i], round);
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(LTHREADS) void greedy_kill_kernel(GreedyArgs a, int round) {
+    __shared__ KillLds s;
+    const int b = blockIdx.y, tiles = a.nty * a.ntx;
+    if (FIRST) {
+        for (int t = blockIdx.x; t < tiles; t += gridDim.x) kill_tile(a, s, b, t, round);
+        return;
+    }
+    const int cur = round & 1;
+    const int n = *ctr_list(a, cur, b);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ctr_dlist(a, b) = 0;                 // the window-mode list of the next round
+    const int *list = a.list + ((long)cur * a.B + b) * tiles;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) kill_tile(a, s, b, list[i], round);
+}
+
+// Whatever the enqueued rounds left alive: one workgroup per image runs further rounds over the image's own tile list.
+// The workgroup reads what it wrote itself in the previous pass (bit maps, lists, dead_round): device-scope fences around
+// the barriers, the counters through atomic loads.  Always launched: it also hands the survivor count to the top-K kernel.
+__global__ __launch_bounds__(KTHREADS) void greedy_tail_kernel(GreedyArgs a, int round0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    KeepLds &sk = *reinterpret_cast<KeepLds *>(smem);
+    KillLds &sl = *reinterpret_cast<KillLds *>(smem + sizeof(KeepLds));
+    const int b = blockIdx.x, tiles = a.nty * a.ntx;
+    for (int round = round0;; ++round) {
+        const int cur = round & 1;
+        const int n = __hip_atomic_load(ctr_list(a, cur, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == 0) break;                                    // uniform: every thread reads the same settled word
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(ctr_list(a, cur ^ 1, b), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int *list = a.list + ((long)cur * a.B + b) * tiles;
+        for (int i = 0; i < n; ++i) keep_tile(a, sk, b, list[i], round);
+        __threadfence();
+        __syncthreads();
+        __threadfence();
+        for (int i = 0; i < n; ++i) kill_tile(a, sl, b, list[i], round);
+        __threadfence();
+        __syncthreads();
+        __threadfence();
+    }
+    if (threadIdx.x == 0) a.counts[b] = __hip_atomic_load(ctr_surv(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // soft_argmax_points (test_utils.py:170-215) on the selected points: the patch is normalised by its sum + 1e-6,
@@ -222,14 +612,52 @@ __global__ void subpixel_kernel(GreedyArgs a, const int32_t *idx, const int32_t 
     o[1] = (float)y + sy / s - (float)pad;
 }
 
+struct Layout {
+    size_t zero_bytes;            // the counters (one line each) + counts [B]: cleared per call
+    size_t off_counts, off_dead, dead_bytes, off_list, off_dlist, off_alive, off_kept, off_surv, total;
+};
+Layout layout(int B, int H, int W) {
+    const size_t ntx = balf_ceil_div(W, TW), nty = balf_ceil_div(H, TH), tiles = ntx * nty;
+    Layout l;
+    l.off_counts = (size_t)4 * B * CTR_STRIDE * sizeof(int);
+    l.zero_bytes = l.off_counts + balf_align_up((size_t)B * sizeof(int), 256);
+    l.off_dead = l.zero_bytes;
+    l.dead_bytes = balf_align_up((size_t)B * tiles * sizeof(int), 256);
+    l.off_list = l.off_dead + l.dead_bytes;
+    l.off_dlist = l.off_list + balf_align_up((size_t)2 * B * tiles * sizeof(int), 256);
+    l.off_alive = l.off_dlist + balf_align_up((size_t)B * tiles * sizeof(int), 256);
+    const size_t map = balf_align_up((size_t)B * H * ntx * sizeof(u64), 256);
+    l.off_kept = l.off_alive + map;
+    l.off_surv = l.off_kept + map;
+    l.total = l.off_surv + (size_t)B * H * W * sizeof(int2);
+    return l;
+}
+
+// hipFuncSetAttribute is a driver round trip: once per kernel and device of the process (as allow_lds32 of detector.hip)
+template <auto Kernel>
+bool allow_lds(int bytes) {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (done.load(std::memory_order_acquire) >> dev & 1) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return false;
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return true;
+}
+
+// rounds enqueued before the tail kernel; BALF_GREEDY_ROUNDS overrides it (read per call: the tests run the tail with 1)
+int rounds_launched() {
+    const char *e = getenv("BALF_GREEDY_ROUNDS");
+    const int v = e ? atoi(e) : ROUNDS_DEFAULT;
+    return v < 1 ? 1 : (v > 256 ? 256 : v);
+}
+
 }  // namespace
 
 extern "C" size_t balf_greedy_nms_workspace_bytes(int B, int H, int W, int K) {
     if (B <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
-    const size_t px = (size_t)B * H * W;
-    const size_t tiles = (size_t)B * balf_ceil_div(W, GT) * balf_ceil_div(H, GT);
-    return balf_align_up(px * 8, 256) + balf_align_up((size_t)B * H * balf_ceil_div(W, GT) * 4, 256) + 256 /*alive*/ +
-           balf_align_up((size_t)B * sizeof(int), 256) + 2 * balf_align_up(tiles * sizeof(int), 256) + px * sizeof(int2);
+    return layout(B, H, W).total;
 }
 
 extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W,
@@ -238,52 +666,60 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
                                int32_t *total_dev, void *workspace_dev, size_t workspace_bytes, void *stream) {
     if (!prob_dev || !idx_dev || !score_dev || !count_dev || !workspace_dev) return BALF_ERR_ARG;
     if (B <= 0 || H <= 0 || W <= 0 || K <= 0 || K > BALF_MAX_TOPK || border < 0) return BALF_ERR_ARG;
+    if (B > 65535) return BALF_ERR_ARG;                       // blockIdx.y
     if (!(conf_thresh > 0.0f) || dist_thresh < 0 || dist_thresh > GD_MAX) return BALF_ERR_ARG;
     if (subpixel_patch < 0 || subpixel_patch > 16 || (subpixel_patch > 0 && !xy_dev)) return BALF_ERR_ARG;
     if (crop_y < 0 || crop_x < 0 || crop_y + H > Hp || crop_x + W > Wp) return BALF_ERR_SHAPE;
     if ((long)H * W > 0x7fffffffL) return BALF_ERR_SHAPE;
-    if (workspace_bytes < balf_greedy_nms_workspace_bytes(B, H, W, K)) return BALF_ERR_WORKSPACE;
+    if ((long)balf_ceil_div(W, TW) * balf_ceil_div(H, TH) * B > 0x7fffffffL) return BALF_ERR_SHAPE;
+    const Layout l = layout(B, H, W);
+    if (workspace_bytes < l.total) return BALF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const size_t px = (size_t)B * H * W;
     char *w = static_cast<char *>(workspace_dev);
-    u64 *key = reinterpret_cast<u64 *>(w); w += balf_align_up(px * 8, 256);
-    unsigned *newk = reinterpret_cast<unsigned *>(w); w += balf_align_up((size_t)B * H * balf_ceil_div(W, GT) * 4, 256);
-    int *alive = reinterpret_cast<int *>(w); w += 256;
-    int *counts = reinterpret_cast<int *>(w); w += balf_align_up((size_t)B * sizeof(int), 256);
-    const size_t n_tiles = (size_t)B * balf_ceil_div(W, GT) * balf_ceil_div(H, GT);
-    int *tile_a = reinterpret_cast<int *>(w); w += balf_align_up(n_tiles * sizeof(int), 256);
-    int *tile_b = reinterpret_cast<int *>(w); w += balf_align_up(n_tiles * sizeof(int), 256);
-    int2 *surv = reinterpret_cast<int2 *>(w);
+    const int ntx = balf_ceil_div(W, TW), nty = balf_ceil_div(H, TH), tiles = ntx * nty;
 
-    GreedyArgs a{prob_dev, Hp, Wp, crop_y, crop_x, H, W, border, conf_thresh, dist_thresh, key, newk, surv, counts,
-                 alive, 0, tile_a, tile_b};
-    if (hipMemsetAsync(counts, 0, balf_align_up((size_t)B * sizeof(int), 256), st) != hipSuccess) return BALF_ERR_LAUNCH;
-    if (hipMemsetAsync(tile_a, 1, n_tiles * sizeof(int), st) != hipSuccess) return BALF_ERR_LAUNCH;   // every tile may be alive
-    const dim3 lin((unsigned)balf_ceil_div((long)H * W, GTHREADS * 4), B), tiles(balf_ceil_div(W, GT), balf_ceil_div(H, GT), B);
-    hipLaunchKernelGGL(greedy_init_kernel, lin, dim3(GTHREADS), 0, st, a);
+    GreedyArgs a{prob_dev, Hp, Wp, crop_y, crop_x, H, W, border, conf_thresh, dist_thresh, B, ntx, nty,
+                 reinterpret_cast<u64 *>(w + l.off_alive), reinterpret_cast<u64 *>(w + l.off_kept),
+                 reinterpret_cast<int *>(w + l.off_dead), reinterpret_cast<int *>(w + l.off_list),
+                 reinterpret_cast<int *>(w + l.off_dlist), reinterpret_cast<int *>(w),
+                 reinterpret_cast<int2 *>(w + l.off_surv), reinterpret_cast<int *>(w + l.off_counts)};
+    if (hipMemsetAsync(w, 0, l.zero_bytes, st) != hipSuccess) return BALF_ERR_LAUNCH;
+    if (hipMemsetAsync(w + l.off_dead, 0x7f, l.dead_bytes, st) != hipSuccess) return BALF_ERR_LAUNCH;   // ALIVE_FOREVER
+    static_assert(ALIVE_FOREVER == 0x7f7f7f7f, "dead_round is initialised by a byte memset");
+
+    constexpr int keep_lds = (int)sizeof(KeepLds), tail_lds = (int)(sizeof(KeepLds) + sizeof(KillLds));
+    static_assert(sizeof(KeepLds) % 16 == 0 && 2 * sizeof(KeepLds) <= 160 * 1024, "two window-mode workgroups per CU");
+    if (!allow_lds<greedy_keep_first_kernel>(keep_lds) || !allow_lds<greedy_keep_window_kernel>(keep_lds) ||
+        !allow_lds<greedy_tail_kernel>(tail_lds))
+        return BALF_ERR_LAUNCH;
+    // round 1 over every tile; rounds 2.. over the lists: launches sized for a full list that return at once on an empty one
+    // (pairwise keep and kill: one wave per tile, the chip holds 8192 of them)
+    const int g1 = tiles < 16384 / B + 64 ? tiles : 16384 / B + 64;
+    const int gw = tiles < 512 / B + 16 ? tiles : 512 / B + 16;
+    const int total = tiles * B;
+    const int first_wg = total < FIRST_WG ? (total + 7) / 8 * 8 : FIRST_WG, per = (total + first_wg - 1) / first_wg;
+    BALF_PROF(balf_prof::kGreedyKeep, st,
+              hipLaunchKernelGGL(greedy_keep_first_kernel, dim3(first_wg), dim3(KTHREADS), keep_lds, st, a, total, per));
+    BALF_PROF(balf_prof::kGreedyKill, st,
+              hipLaunchKernelGGL(greedy_kill_kernel<true>, dim3(tiles, B), dim3(LTHREADS), 0, st, a, 1));
     BALF_LAUNCH_CHECK();
-    // rounds in groups of 4; the last kill of a group counts the candidates still alive, read back with ONE
-    // stream synchronisation per group (the only entry point of the library that synchronises)
-    for (int round = 0;; round += 4) {
-        if (round > 4096) return BALF_ERR_LAUNCH;      // cannot happen: every round keeps >= 1 per alive region
-        if (hipMemsetAsync(alive, 0, sizeof(int), st) != hipSuccess) return BALF_ERR_LAUNCH;
-        for (int r = 0; r < 4; ++r) {
-            a.count_alive = (r == 3);
-            BALF_PROF(balf_prof::kGreedyKeep, st, hipLaunchKernelGGL(greedy_keep_kernel, tiles, dim3(GTHREADS), 0, st, a));
-            BALF_PROF(balf_prof::kGreedyKill, st, hipLaunchKernelGGL(greedy_kill_kernel, tiles, dim3(GTHREADS), 0, st, a));
-            int *t = const_cast<int *>(a.tile_in); a.tile_in = a.tile_out; a.tile_out = t;   // ping-pong the tile counts
-        }
-        BALF_LAUNCH_CHECK();
-        int h_alive = 0;
-        if (hipMemcpyAsync(&h_alive, alive, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess)
-            return BALF_ERR_LAUNCH;
-        if (h_alive == 0) break;
+    const int rounds = rounds_launched();
+    for (int r = 2; r <= rounds; ++r) {
+        BALF_PROF(balf_prof::kGreedyKeep, st,
+                  hipLaunchKernelGGL(greedy_keep_sparse_kernel, dim3(g1, B), dim3(LTHREADS), 0, st, a, r));
+        BALF_PROF(balf_prof::kGreedyKeep, st,
+                  hipLaunchKernelGGL(greedy_keep_window_kernel, dim3(gw, B), dim3(KTHREADS), keep_lds, st, a, r));
+        BALF_PROF(balf_prof::kGreedyKill, st,
+                  hipLaunchKernelGGL(greedy_kill_kernel<false>, dim3(g1, B), dim3(LTHREADS), 0, st, a, r));
     }
-    if (total_dev && hipMemcpyAsync(total_dev, counts, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    BALF_LAUNCH_CHECK();
+    BALF_PROF(balf_prof::kGreedyKill, st,
+              hipLaunchKernelGGL(greedy_tail_kernel, dim3(B), dim3(KTHREADS), tail_lds, st, a, rounds + 1));
+    BALF_LAUNCH_CHECK();
+    if (total_dev && hipMemcpyAsync(total_dev, a.counts, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return BALF_ERR_LAUNCH;
     // the K best kept points by score, sorted (score desc, index asc); count_dev = rows returned (<= K)
-    int rc = balf_topk_select_launch(surv, counts, (long)H * W, B, K, /*zero_fallback=*/0, idx_dev, score_dev,
+    int rc = balf_topk_select_launch(a.surv, a.counts, (long)H * W, B, K, /*zero_fallback=*/0, idx_dev, score_dev,
                                      count_dev, st, /*thr_explicit=*/0u);
     if (rc != BALF_OK) return rc;
     if (subpixel_patch > 0) {

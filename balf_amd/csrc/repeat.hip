@@ -114,8 +114,9 @@ __global__ __launch_bounds__(1024) void rep_scan_kernel(const int *cnt_s, const 
 }
 
 __global__ __launch_bounds__(64) void rep_fill_kernel(const double *src, int ns, const double *dst, int nd, RepParams p,
-                                                      const int *off_s, const int *off_m, unsigned long long *key_s,
-                                                      unsigned *val_s, unsigned long long *key_m, unsigned *val_m) {
+                                                      const int *off_s, const int *off_m, int max_edges,
+                                                      unsigned long long *key_s, unsigned *val_s, unsigned long long *key_m,
+                                                      unsigned *val_m) {
     const int i = blockIdx.x, lane = threadIdx.x;
     const double sx = src[3 * i], sy = src[3 * i + 1], sr = src[3 * i + 2];
     int ws = off_s[i], wm = off_m[i];
@@ -126,17 +127,26 @@ __global__ __launch_bounds__(64) void rep_fill_kernel(const double *src, int ns,
         const bool ks = j < nd && s >= p.thr, km = j < nd && m >= p.thr;
         const unsigned long long bs = __ballot(ks), bm = __ballot(km);
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (ks) { const int o = ws + __popcll(bs & below); key_s[o] = __double_as_longlong(s); val_s[o] = (unsigned)(i * nd + j); }
-        if (km) { const int o = wm + __popcll(bm & below); key_m[o] = __double_as_longlong(m); val_m[o] = (unsigned)(i * nd + j); }
+        // a list longer than the caller's max_edges is cut here and reported by rep_greedy_kernel (count -1): the host never
+        // learns the length, so nothing waits for it
+        if (ks) { const int o = ws + __popcll(bs & below); if (o < max_edges) { key_s[o] = __double_as_longlong(s); val_s[o] = (unsigned)(i * nd + j); } }
+        if (km) { const int o = wm + __popcll(bm & below); if (o < max_edges) { key_m[o] = __double_as_longlong(m); val_m[o] = (unsigned)(i * nd + j); } }
         ws += __popcll(bs); wm += __popcll(bm);
     }
 }
 
 // out: found[which], err[which], corr[which][k] = (x_pos = dst index, y_pos = src index) in assignment order
-__global__ __launch_bounds__(64) void rep_greedy_kernel(const unsigned long long *keys, const unsigned *vals, int n_edges, int nd,
-                                                        int *found_out, double *err_out, int *corr, int cap) {
+// *n_edges_dev > max_edges (the candidate list did not fit the workspace): found = -1, no correspondences
+__global__ __launch_bounds__(64) void rep_greedy_kernel(const unsigned long long *keys, const unsigned *vals, const int *n_edges_dev,
+                                                        int max_edges, int nd, int *found_out, double *err_out, int *corr, int cap) {
     __shared__ unsigned vis_x[kMaxPoints / 32], vis_y[kMaxPoints / 32];
     const int lane = threadIdx.x;
+    const int n_edges = *n_edges_dev;
+    if (n_edges > max_edges) {
+        if (lane == 0) { *found_out = -1; *err_out = 0.0; }
+        for (int k = lane; k < cap; k += 64) { corr[2 * k] = -1; corr[2 * k + 1] = -1; }
+        return;
+    }
     for (int k = lane; k < kMaxPoints / 32; k += 64) { vis_x[k] = 0u; vis_y[k] = 0u; }
     __syncthreads();
     int found = 0;
@@ -191,9 +201,11 @@ __global__ void homography_kernel(const double *pts, int n, const double *h, dou
 // (Round 2 called hipcub::DeviceRadixSort here; the library now has no third-party device code.)
 constexpr int kSortWaves = 16;
 __global__ __launch_bounds__(kSortWaves * 64) void rep_sort_kernel(unsigned long long *k0, unsigned *v0, unsigned long long *k1,
-                                                                  unsigned *v1, int n) {
+                                                                  unsigned *v1, const int *n_dev, int max_edges) {
     __shared__ int hist[16][kSortWaves];
     __shared__ int uniform_digit;
+    const int n = *n_dev;
+    if (n <= 0 || n > max_edges) return;                          // nothing to sort / overflow (reported by rep_greedy_kernel)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per = ((n + kSortWaves - 1) / kSortWaves + 63) / 64 * 64;
     const int lo = wave * per < n ? wave * per : n, hi = lo + per < n ? lo + per : n;
@@ -301,21 +313,18 @@ extern "C" int balf_repeatability(const double *src_dev, int ns, const double *d
     BALF_LAUNCH_CHECK();
     rep_scan_kernel<<<1, 1024, 0, st>>>(w.cnt_s, w.cnt_m, w.poss, ns, w.off_s, w.off_m, w.totals);
     BALF_LAUNCH_CHECK();
-    int totals[3] = {0, 0, 0};
-    if (hipMemcpyAsync(totals, w.totals, sizeof(totals), hipMemcpyDeviceToHost, st) != hipSuccess) return BALF_ERR_LAUNCH;
-    if (hipStreamSynchronize(st) != hipSuccess) return BALF_ERR_LAUNCH;
-    if (totals[0] > max_edges || totals[1] > max_edges) return BALF_ERR_WORKSPACE;
-    rep_fill_kernel<<<ns, 64, 0, st>>>(src_dev, ns, dst_dev, nd, p, w.off_s, w.off_m, w.key_s, w.val_s, w.key_m, w.val_m);
+    // the list lengths stay on the device (round 5 read them back behind a hipStreamSynchronize): the fill pass cuts a list
+    // at max_edges, the sort and assignment kernels read the length themselves
+    rep_fill_kernel<<<ns, 64, 0, st>>>(src_dev, ns, dst_dev, nd, p, w.off_s, w.off_m, max_edges, w.key_s, w.val_s, w.key_m, w.val_m);
     BALF_LAUNCH_CHECK();
     const int cap = ns < nd ? ns : nd;
     for (int which = 0; which < 2; ++which) {
-        const int ne = totals[which];
-        if (ne > 0) {       // (sorts in place between the candidate list and the output buffers; the list is not needed again)
-            rep_sort_kernel<<<1, kSortWaves * 64, 0, st>>>(which ? w.key_m : w.key_s, which ? w.val_m : w.val_s, w.key_out, w.val_out, ne);
-            BALF_LAUNCH_CHECK();
-        }
-        rep_greedy_kernel<<<1, 64, 0, st>>>(w.key_out, w.val_out, ne, nd, counts_dev + which, errors_dev + which,
-                                            which ? corr_m_dev : corr_s_dev, cap);
+        // (sorts between the candidate list and the output buffers; the list is not needed again)
+        rep_sort_kernel<<<1, kSortWaves * 64, 0, st>>>(which ? w.key_m : w.key_s, which ? w.val_m : w.val_s, w.key_out, w.val_out,
+                                                      w.totals + which, max_edges);
+        BALF_LAUNCH_CHECK();
+        rep_greedy_kernel<<<1, 64, 0, st>>>(w.key_out, w.val_out, w.totals + which, max_edges, nd, counts_dev + which,
+                                            errors_dev + which, which ? corr_m_dev : corr_s_dev, cap);
         BALF_LAUNCH_CHECK();
     }
     if (hipMemcpyAsync(counts_dev + 2, w.totals + 2, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return BALF_ERR_LAUNCH;

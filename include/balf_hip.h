@@ -17,10 +17,10 @@
  * Conventions: plain pointers and sizes only.  Every device buffer (inputs, outputs, workspace)
  * is owned by the caller; the library never allocates or frees device memory, never calls
  * hipDeviceSynchronize, and enqueues all work on the hipStream_t passed as `stream`
- * (as void*; NULL = the null stream).  It does not synchronise the stream either, with two exceptions whose
- * work is data dependent and that say so where they are declared: balf_greedy_nms (hipStreamSynchronize once per
- * group of 4 suppression rounds) and balf_repeatability (once, for the candidate count).  Every function returns BALF_OK (0) or a negative
- * BALF_ERR_* code and never throws.  Shapes are validated on the host before any launch.
+ * (as void*; NULL = the null stream).  No entry point synchronises the stream or reads anything back: where the amount
+ * of work depends on the data (the rounds of balf_greedy_nms, the candidate pairs of balf_repeatability) the kernels
+ * decide on the device, and a result that did not fit is reported in the outputs.  Every function returns BALF_OK (0)
+ * or a negative BALF_ERR_* code and never throws.  Shapes are validated on the host before any launch.
  */
 #ifndef BALF_HIP_H
 #define BALF_HIP_H
@@ -113,7 +113,10 @@ int balf_forward_u8(const void *packed_dev, int precision, const unsigned char *
  *   status[BALF_STATUS_SE]    = 1   a squeeze-excite pre-activation was not finite (SE kernel);
  *   status[3]                       reserved (never written).
  * The words are valid once the stream has passed the call.  status_dev may be NULL (then these are balf_forward /
- * balf_forward_u8).  The exact-fp32 path (BALF_PREC_FP32) has no operand range to leave and reports BALF_STATUS_SCORE only.
+ * balf_forward_u8).  The exact-fp32 path (BALF_PREC_FP32) has no operand range to leave: it reports BALF_STATUS_SCORE and
+ * BALF_STATUS_SE (its SE kernel is the same one).  BALF_STATUS_RANGE covers STAGE BOUNDARIES only (a stage's output, the
+ * head's input, conv2's output); an overflow inside a stage (token mix, dense2 inputs) is seen only if it reaches a
+ * boundary, the SE pre-activation or the softmax denominator; NaNs do not raise RANGE (the comparison is false for them).
  * Host mirror: MLP_MA_DECODER checks the block lazily and re-runs a flagged batch on the fp32 kernels. */
 #define BALF_STATUS_SCORE 0
 #define BALF_STATUS_RANGE 1
@@ -176,8 +179,9 @@ int balf_nms_threshold(const float *prob_dev, int B, int Hp, int Wp, int crop_y,
  * candidate lies within Chebyshev distance dist_thresh (<= 16).  Output rows sorted by score descending (flat
  * index ascending among equal scores): idx_dev[B,K] (-1 padded), score_dev[B,K], count_dev[B] = rows returned
  * (<= K), total_dev[B] = points kept before truncation (may be NULL).  subpixel_patch > 0 additionally writes
- * xy_dev[B,K,2] = (x, y) refined by the patch soft-argmax.  NOTE: the number of suppression rounds is data
- * dependent, so this entry point calls hipStreamSynchronize(stream) once per group of 4 rounds. */
+ * xy_dev[B,K,2] = (x, y) refined by the patch soft-argmax.  The number of suppression rounds depends on the data
+ * (4-8 on score maps, ~W / dist_thresh on a monotone ramp): a fixed number of rounds is enqueued, each returning at
+ * once when nothing is alive, and a per-image kernel finishes whatever is left -- exact for every input, stream-ordered. */
 size_t balf_greedy_nms_workspace_bytes(int B, int H, int W, int K);
 int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int crop_x, int H, int W, int border,
                     float conf_thresh, int dist_thresh, int K, int subpixel_patch, int32_t *idx_dev,
@@ -254,9 +258,10 @@ int balf_match_smnn(const float *desc1_dev, int n1, const float *desc2_dev, int 
  * possible_matches}; errors_dev[2] = the two sums of (1 - overlap) over the assigned pairs, in assignment order;
  * corr_s_dev / corr_m_dev [min(ns,nd),2] = (dst index, src index) per assigned pair in assignment order, -1 padded.
  * Among exactly equal overlaps the pair with the lower flat index ns-major wins (the reference's order there is
- * NumPy's unstable argsort).  max_edges bounds the number of pairs whose overlap reaches 1 - overlap_err
- * (BALF_ERR_WORKSPACE when exceeded).  The candidate count is data dependent: this entry point calls
- * hipStreamSynchronize(stream) once.  ns, nd <= 65536.
+ * NumPy's unstable argsort).  max_edges bounds the number of pairs whose overlap reaches 1 - overlap_err, per scale;
+ * that number is known on the device only: when a scale's list does not fit, its entry of counts_dev is -1 and its
+ * correspondences are all -1 (the host mirror raises when it reads that) -- nothing waits for the device.
+ * ns, nd <= 65536.
  * balf_apply_homography replaces apply_homography_to_points, balf/benchmark_test/geometry_tools.py:43-86:
  * points_dev [n,4] float64 rows (x, y, radius, score), h_dev[9] row-major -> out_dev [n,4]. */
 size_t balf_repeatability_workspace_bytes(int ns, int nd, int max_edges);

@@ -116,3 +116,73 @@ def test_subpixel_against_reference_code(name, patch):
     assert np.array_equal(pts[:, 2], ref[:, 2])
     err = float(np.abs(pts[:, :2] - ref[:, :2]).max())
     assert err < 2e-5, err
+
+
+def _greedy_vs_oracle(m, conf, dist, border=0):
+    from balf_amd import ops
+    h, w = m.shape
+    ri, rs = O.greedy_nms(O.remove_borders(m, border), conf, dist)
+    k = min(h * w, 16384)
+    idx, sc, _, cnt, tot = ops.greedy_nms(torch.from_numpy(m).cuda().unsqueeze(0), 0, 0, h, w, border, conf, dist, k, 0)
+    n = int(cnt[0])
+    assert int(tot[0]) == len(ri) and n == min(k, len(ri))
+    assert np.array_equal(idx[0, :n].cpu().numpy(), np.asarray(ri[:n], np.int32))
+    assert np.array_equal(sc[0, :n].cpu().numpy().view(np.uint32), np.asarray(rs[:n], np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("rounds", ["1", "2", "3"])
+def test_greedy_tail_kernel_finishes_the_rounds(rounds, monkeypatch):
+    """Round 6: the rounds are enqueued without looking at the data; what is alive after them is finished by the per-image
+    tail kernel.  With BALF_GREEDY_ROUNDS = 1..3 the tail does (nearly) all the work: goldens and random maps bit-exact."""
+    from balf_amd import ops
+    monkeypatch.setenv("BALF_GREEDY_ROUNDS", rounds)
+    f = np.load(os.path.join(G, "greedy_nms.npz"))
+    for name, spec in cases.GREEDY_CASES.items():
+        t = torch.from_numpy(cases.nms_input(spec)).cuda().unsqueeze(0)
+        idx, sc, _, cnt, tot = ops.greedy_nms(t, 0, 0, spec["h"], spec["w"], spec["border"], spec["conf"], spec["nms"], 4096)
+        n = int(cnt[0])
+        assert n == int(tot[0]) == f[name + ".idx"].size, name
+        assert np.array_equal(idx[0, :n].cpu().numpy(), f[name + ".idx"]), name
+    rng = np.random.default_rng(77)
+    for case in range(12):
+        h, w = int(rng.integers(40, 200)), int(rng.integers(40, 300))
+        m = rng.random((h, w), dtype=np.float32)
+        if case % 2:
+            m = (np.round(m * 10) / 10).astype(np.float32)
+        _greedy_vs_oracle(m, 0.05, int(rng.integers(1, 17)), int(rng.integers(0, 4)))
+
+
+def test_greedy_monotone_ramp_and_plateau():
+    """The adversarial inputs of the parallel form: a monotone ramp (one kept point per window and round along the slope:
+    ~W/d rounds, far beyond the enqueued ones, all tiles in window mode) and a constant plateau (every comparison a tie,
+    raster-first wins)."""
+    h, w = 96, 700
+    yy, xx = np.mgrid[0:h, 0:w]
+    for ramp in (xx + 0.001 * yy, -xx - 0.001 * yy, yy * w + xx, -(yy * w + xx)):
+        m = (0.1 + 0.8 * (ramp - ramp.min()) / (ramp.max() - ramp.min())).astype(np.float32)
+        _greedy_vs_oracle(m, 0.05, 5)
+    _greedy_vs_oracle(np.full((h, w), 0.5, np.float32), 0.05, 7)
+    _greedy_vs_oracle(np.full((70, 130), 0.5, np.float32), 0.05, 16, border=3)
+
+
+def test_greedy_is_stream_ordered():
+    """balf_greedy_nms enqueues and returns: behind a kernel that keeps the stream busy for a while the call comes back
+    long before that kernel ends (round 5 synchronised the stream once per four rounds)."""
+    import time
+    from balf_amd import ops
+    rng = np.random.default_rng(5)
+    t = torch.from_numpy(rng.random((4, 256, 320), dtype=np.float32)).cuda()
+    ops.greedy_nms(t, 0, 0, 256, 320, 4, 0.015, 15, 512, 5)               # warm: workspace, attributes
+    torch.cuda.synchronize()
+    done = torch.cuda.Event()
+    torch.cuda._sleep(int(1.5e9))                                          # ~0.7 s of device time
+    t0 = time.perf_counter()
+    idx, sc, xy, cnt, tot = ops.greedy_nms(t, 0, 0, 256, 320, 4, 0.015, 15, 512, 5)
+    dt = time.perf_counter() - t0
+    done.record()
+    busy = not done.query()
+    torch.cuda.synchronize()
+    assert busy, "the stream had drained when balf_greedy_nms returned: it waited for the device"
+    assert dt < 0.1, f"balf_greedy_nms took {dt * 1e3:.1f} ms of host time behind a busy stream"
+    ri, _ = O.greedy_nms(O.remove_borders(t[1].cpu().numpy(), 4), 0.015, 15)
+    assert np.array_equal(idx[1, :int(cnt[1])].cpu().numpy(), np.asarray(ri[:512], np.int32))

@@ -107,3 +107,45 @@ def test_common_region_masks_identity_is_the_inner_frame():
     ms, md = geometry_tools.create_common_region_masks(np.eye(3), (100, 140), (100, 140))
     ref = np.zeros((100, 140)); ref[15:85, 15:125] = 1.0
     assert np.array_equal(ms, ref) and np.array_equal(md, ref)
+
+
+def test_repeatability_overflow_is_reported_without_a_sync(monkeypatch):
+    """Round 6: balf_repeatability no longer reads the candidate count back (no hipStreamSynchronize); a list longer than
+    max_edges is cut on the device and reported as count -1, which the host mirror turns into an error."""
+    import time
+    import torch
+    from balf_amd._lib import BalfHipError
+    from balf_amd.benchmark_test import repeatability_tools as R
+    rng = np.random.default_rng(1)
+    pts = np.concatenate([rng.uniform(50, 60, (300, 2)), np.full((300, 1), 20.0)], axis=1)      # 300 x 300 overlapping discs
+    ref = R.compute_repeatability(pts, pts + 0.25)
+    assert ref["num_points_single_scale"] > 0
+    monkeypatch.setattr(R, "MAX_EDGES", 1000)
+    with pytest.raises(BalfHipError, match="candidate pairs"):
+        R.compute_repeatability(pts, pts + 0.25)
+    monkeypatch.setattr(R, "MAX_EDGES", 1 << 22)
+    # stream order: behind a busy stream the library call returns at once (the mirror's .cpu() is what waits)
+    from balf_amd import ops
+    from balf_amd._lib import check, current_stream_ptr, lib
+    dev = torch.device("cuda:0")
+    s = torch.from_numpy(pts).to(dev)
+    d = torch.from_numpy(pts + 0.25).to(dev)
+    counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    errors = torch.zeros(2, dtype=torch.float64, device=dev)
+    cs = torch.empty((300, 2), dtype=torch.int32, device=dev)
+    cm = torch.empty((300, 2), dtype=torch.int32, device=dev)
+    cap = 300 * 300
+    ws = ops._workspace("repeat", dev, lib().balf_repeatability_workspace_bytes(300, 300, cap))
+    torch.cuda.synchronize()
+    done = torch.cuda.Event()
+    torch.cuda._sleep(int(1.5e9))
+    t0 = time.perf_counter()
+    check(lib().balf_repeatability(s.data_ptr(), 300, d.data_ptr(), 300, 0.4, 1e-6, 3.0, 30.0, cap, counts.data_ptr(),
+                                   errors.data_ptr(), cs.data_ptr(), cm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                   current_stream_ptr(dev)), "balf_repeatability")
+    dt = time.perf_counter() - t0
+    done.record()
+    busy = not done.query()
+    torch.cuda.synchronize()
+    assert busy and dt < 0.1, (busy, dt)
+    assert int(counts[0]) == ref["num_points_single_scale"] and int(counts[1]) == ref["num_points_multi_scale"]
