@@ -92,26 +92,44 @@ def _down(cin, c, a):
     return d
 
 
+_GUARD_SLOTS = 8
+
+
+class _PendingCall:
+    """A guarded split-f16 forward that has not been looked at yet.  Holds NO tensor: scalars, an event recorded behind the
+    call and weak references to its input and outputs, so that a batch the caller has dropped is freed at once (ADVICE r5:
+    the closure kept here before pinned ~1.3 GB at 32 x 1080p until the next forward)."""
+    __slots__ = ("ev", "wkey", "slot", "seq", "kind", "dims", "refs")
+
+    def __init__(self, ev, wkey, slot, seq, kind, dims, refs):
+        self.ev, self.wkey, self.slot, self.seq, self.kind, self.dims, self.refs = ev, wkey, slot, seq, kind, dims, refs
+
+
 class _Fp16Guard:
-    """The status block of the split-f16 forwards on one device (include/balf_hip.h: balf_forward_status): four ints in PINNED
-    HOST memory that the kernels store into when a softmax denominator is not finite or a stage output reaches the largest
-    f16 -- the host reads them without a copy -- plus what is needed to repair the last call if it turns out to be flagged:
-    an event recorded behind it and weak references to its input and outputs."""
+    """The status blocks of the split-f16 forwards on one device (include/balf_hip.h: balf_forward_status): a RING of
+    _GUARD_SLOTS blocks of four ints in PINNED HOST memory.  Every guarded call gets a block of its own, so that a word raised by
+    call A is attributed to A however far the host has run ahead (with one shared block a flag of A was charged to whatever call
+    happened to be pending when the host looked); the kernels store into it when a softmax denominator is not finite or
+    a stage output reaches the largest f16, the host reads it without a copy.  `pending`: the calls not yet looked at, oldest
+    first."""
 
     def __init__(self, device):
+        import collections
         with torch.inference_mode(False):   # (a NORMAL tensor even when the first forward runs under torch.inference_mode(): an
             # inference tensor could not be cleared from outside that mode later)
-            self.words = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32).pin_memory()
+            self.words = torch.zeros(_GUARD_SLOTS * _lib.STATUS_WORDS, dtype=torch.int32).pin_memory()
         self.device = device
-        self.pending = None            # (event, weights key, call) of the last guarded forward, not yet looked at
+        self.pending = collections.deque()
+        self.seq = 0
 
-    def ptr(self) -> int:
-        return self.words.data_ptr()
+    def ptr(self, slot: int) -> int:
+        return self.words.data_ptr() + slot * _lib.STATUS_WORDS * 4
 
-    def read_and_clear(self):
-        w = self.words.tolist()
+    def read_and_clear(self, slot: int):
+        v = self.words[slot * _lib.STATUS_WORDS:(slot + 1) * _lib.STATUS_WORDS]
+        w = v.tolist()
         if any(w):
-            self.words.zero_()
+            v.zero_()
         return w
 
 
@@ -251,8 +269,8 @@ class MLP_MA_DECODER(nn.Module):
         the HIP library, ~2.5x slower) and the module says so -- or raises with BALF_FP16_STRICT=1.  The requested
         precision is left alone: the next checkpoint is judged afresh."""
         g = self._guard.get(device)
-        if g is not None and g.pending is not None and not getattr(self, "_validating", False):
-            self._guard_look(g, final=False)                     # lazy look at the previous call's status block (no wait)
+        if g is not None and g.pending and not getattr(self, "_validating", False):
+            self._guard_look(g, final=False)                     # lazy look at the finished calls' status blocks (no wait)
         wkey = self._weights_key(device)
         prec = self.precision
         if prec == "fp16" and not getattr(self, "_validating", False) and self._fp16_verdict is not None \
@@ -307,83 +325,109 @@ class MLP_MA_DECODER(nn.Module):
         logits = torch.empty((b, 65, h // 8, w // 8), dtype=torch.float32, device=dev) if want_logits else None
         nbytes = l.balf_forward_workspace_bytes(b, h, w)
 
-        def run(blob_, prec_, status):
-            ws = ops._workspace("forward", dev, nbytes)
-            with torch.cuda.device(dev):
-                check(l.balf_forward_status(blob_.data_ptr(), self._code_of(prec_), x.data_ptr(), b, h, w,
-                                            logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
-                                            ws.numel(), status, _lib.current_stream_ptr(dev)), "balf_forward")
-        self._guarded_call(dev, prec, blob, run, (x, prob, logits))
+        self._guarded_call(dev, prec, blob, "f32", (b, h, w, nbytes), (x, prob, logits))
         return {"logits": logits, "prob": prob}
 
+    def _launch(self, kind, dims, blob, prec, status, src, prob, logits):
+        """One balf_forward_status / balf_forward_u8_status on the current stream of prob's device (``status``: pointer or None)."""
+        l = lib()
+        dev = prob.device
+        ws = ops._workspace("forward", dev, dims[-1])
+        lg = logits.data_ptr() if logits is not None else None
+        with torch.cuda.device(dev):
+            if kind == "f32":
+                b, h, w, _ = dims
+                check(l.balf_forward_status(blob.data_ptr(), self._code_of(prec), src.data_ptr(), b, h, w, lg, prob.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), status, _lib.current_stream_ptr(dev)), "balf_forward")
+            else:
+                ch, b, h, w, _ = dims
+                check(l.balf_forward_u8_status(blob.data_ptr(), self._code_of(prec), src.data_ptr(), ch, b, h, w, lg,
+                                               prob.data_ptr(), ws.data_ptr(), ws.numel(), status,
+                                               _lib.current_stream_ptr(dev)), "balf_forward_u8")
+
     # ---- the split-f16 path on inputs nobody has seen (VERDICT r4 item 3) ----------------------
-    def _guarded_call(self, dev, prec, blob, run, tensors):
-        """Run one forward (``run(blob, precision, status pointer or None)``).  On the split-f16 path the kernels get the
-        module's status block; what it says is acted on according to BALF_FP16_GUARD (see _guard_mode):
-        a flagged batch is re-run on the exact-fp32 kernels INTO THE SAME OUTPUT TENSORS -- stream-ordered, so every later GPU
-        consumer sees the repaired values -- the module warns (BALF_FP16_STRICT=1: raises) and these weights run on the fp32
-        kernels from then on (effective_precision says so).  In lazy mode the repair happens when the next forward starts
-        and only if the caller still holds the flagged call's input and outputs; a host copy taken in between is not
-        recalled -- use BALF_FP16_GUARD=sync (or validate_fp16) where that matters."""
+    def _guarded_call(self, dev, prec, blob, kind, dims, tensors):
+        """Run one forward (``_launch(kind, dims, ...)`` on ``tensors`` = (input, prob, logits or None)).  On the split-f16
+        path the kernels get a status block of the call's own (a ring of _GUARD_SLOTS); what it says is acted on according to
+        BALF_FP16_GUARD (see _guard_mode): a flagged batch is re-run on the exact-fp32 kernels INTO THE SAME OUTPUT TENSORS, the
+        module warns (BALF_FP16_STRICT=1: raises) and these weights run on the fp32 kernels from then on (effective_precision
+        says so).  ``sync``: that happens before the forward returns -- nobody sees a flagged value.  ``lazy`` (default): the
+        look happens when a later forward starts (or in fp16_guard_check()), never with a wait on the hot path; the repair is
+        stream-ordered, so GPU work enqueued AFTER it sees the repaired tensors, but what was enqueued between the flagged call
+        and the look (the NMS of pipeline.detect_batch, a copy to the host) has used the split path's values: the warning names
+        the call and says how many later ones had been enqueued -- repeat those, or run with BALF_FP16_GUARD=sync where that
+        matters.  Only weak references are kept: outputs the caller has dropped are not repaired (and not kept alive)."""
         mode = _guard_mode()
         if prec != "fp16" or mode == "off" or getattr(self, "_validating", False):
-            run(blob, prec, None)
+            self._launch(kind, dims, blob, prec, None, *tensors)
             return
         g = self._guard.get(dev)
         if g is None:
             g = self._guard[dev] = _Fp16Guard(dev)
-        run(blob, prec, g.ptr())
+        if len(g.pending) >= _GUARD_SLOTS:                       # the host is a whole ring ahead: the oldest call's block is
+            g.pending[0].ev.synchronize()                        # needed again -- wait for that call (only) and look at it
+            self._guard_look(g, final=False)
+        slot = g.seq % _GUARD_SLOTS
+        g.seq += 1
+        self._launch(kind, dims, blob, prec, g.ptr(slot), *tensors)
         import weakref
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         refs = tuple(weakref.ref(t) if t is not None else None for t in tensors)
-        g.pending = (ev, self._last_wkey, run, refs)
+        g.pending.append(_PendingCall(ev, self._last_wkey, slot, g.seq, kind, dims, refs))
         if mode == "sync":
             ev.synchronize()
             self._guard_look(g, final=True)
 
     def _guard_look(self, g, final: bool):
-        """Look at the status block behind the pending call.  ``final``: the stream has passed it."""
-        pend = g.pending
-        if pend is None:
-            return
-        ev, wkey, run, refs = pend
-        if not final and not ev.query():
-            return                      # still running: the words are sticky, the next look sees them
-        g.pending = None
-        words = g.read_and_clear()
-        if not any(words):
-            return
+        """Look at the status blocks of the pending calls the stream has passed, oldest first (``final``: it has passed all)."""
+        while g.pending:
+            p = g.pending[0]
+            if not final and not p.ev.query():
+                return                  # still running: its block is its own, a later look sees it
+            g.pending.popleft()
+            words = g.read_and_clear(p.slot)
+            if any(words):
+                self._guard_act(g, p, words, later=len(g.pending))
+
+    def _guard_act(self, g, p, words, later: int):
         # Any word is a reason to leave the split path: beyond 65504 the high half saturates and the low half alone (11 bits)
         # carries the excess -- ~3e-4 relative instead of 2^-20 --, beyond ~1.3e5 the products turn into inf / NaN.
-        msg = ("an operand of the split-f16 path left the range of its f16 halves on a caller's input (status words "
-               f"score={words[0]} range={words[1]} se={words[2]}: non-finite score map / stage output >= 65504 / non-finite "
-               "squeeze-excite)")
+        msg = (f"an operand of the split-f16 path left the range of its f16 halves on a caller's input (guarded call #{p.seq}, "
+               f"status words score={words[0]} range={words[1]} se={words[2]}: non-finite score map / stage output >= 65504 / "
+               "non-finite squeeze-excite)")
         if os.environ.get("BALF_FP16_STRICT") == "1":
             raise BalfHipError(msg + "; use precision='fp32' for this checkpoint")
         # these weights run on the exact-fp32 kernels from now on ...
         dev = g.device
-        if self._weights_key(dev) == wkey:
-            self._fp16_verdict = (wkey, "fp32")
-        live = [r() if r is not None else None for r in refs]
+        same_weights = self._weights_key(dev) == p.wkey
+        if same_weights:
+            self._fp16_verdict = (p.wkey, "fp32")
+        src, prob, logits = (r() if r is not None else None for r in p.refs)
         repaired = False
-        if live[0] is not None and live[1] is not None and self._weights_key(dev) == wkey:
-            # ... and the flagged batch is computed again into the tensors the caller holds
-            run(self.packed_weights(dev, "fp32", wkey), "fp32", None)
+        if src is not None and prob is not None and same_weights:
+            # ... and the flagged batch is computed again into the tensors the caller still holds
+            self._launch(p.kind, p.dims, self.packed_weights(dev, "fp32", p.wkey), "fp32", None, src, prob, logits)
             repaired = True
+        del src, prob, logits
         self._effective = "fp32"
-        warnings.warn("balf_amd: " + msg + ("; that batch was re-run on the exact-fp32 kernels into the same output tensors"
-                                            if repaired else "; its outputs could not be repaired (input or outputs released)") +
-                      ", and this checkpoint runs on the fp32 kernels from now on (effective_precision='fp32')", RuntimeWarning)
+        how = ("; that batch was re-run on the exact-fp32 kernels into the same output tensors" if repaired
+               else "; its outputs could not be repaired (input or outputs released)")
+        if later:
+            how += (f" after {later} later forward(s) had been enqueued -- GPU work enqueued between call #{p.seq} and now used "
+                    "the split path's values: repeat it, or run with BALF_FP16_GUARD=sync")
+        warnings.warn("balf_amd: " + msg + how + ", and this checkpoint runs on the fp32 kernels from now on "
+                      "(effective_precision='fp32')", RuntimeWarning)
 
     def fp16_guard_check(self, synchronize: bool = True) -> bool:
-        """Act on the status block of the last split-f16 forward now (see _guarded_call); ``synchronize`` waits for it.
-        Returns True when a flag was found and acted on -- a caller that has already copied that call's results to the host
-        (pipeline.extract_detections, demo_match.detect: the reference's one-image-per-call pattern) repeats its call then."""
+        """Act on the status blocks of the split-f16 forwards so far now (see _guarded_call); ``synchronize`` waits for them.
+        Returns True when a flag was found and acted on -- a caller that has already used that call's results (copied them to
+        the host like pipeline.extract_detections and demo_match.detect, the reference's one-image-per-call pattern, or fed them
+        to further kernels like pipeline.detect_batch) repeats its call then."""
         hit = False
         for g in self._guard.values():
-            if g.pending is not None and synchronize:
-                g.pending[0].synchronize()
+            if g.pending and synchronize:
+                g.pending[-1].ev.synchronize()
             before = self._fp16_verdict
             self._guard_look(g, final=synchronize)
             hit = hit or (self._fp16_verdict is not before and self._fp16_verdict is not None and self._fp16_verdict[1] == "fp32")
@@ -461,11 +505,5 @@ class MLP_MA_DECODER(nn.Module):
         logits = torch.empty((b, 65, hp // 8, wp // 8), dtype=torch.float32, device=dev) if want_logits else None
         nbytes = l.balf_forward_workspace_bytes(b, hp, wp)
 
-        def run(blob_, prec_, status):
-            ws = ops._workspace("forward", dev, nbytes)
-            with torch.cuda.device(dev):
-                check(l.balf_forward_u8_status(blob_.data_ptr(), self._code_of(prec_), images.data_ptr(), ch, b, h, w,
-                                               logits.data_ptr() if want_logits else None, prob.data_ptr(), ws.data_ptr(),
-                                               ws.numel(), status, _lib.current_stream_ptr(dev)), "balf_forward_u8")
-        self._guarded_call(dev, prec, blob, run, (images, prob, logits))
+        self._guarded_call(dev, prec, blob, "u8", (ch, b, h, w, nbytes), (images, prob, logits))
         return {"logits": logits, "prob": prob}

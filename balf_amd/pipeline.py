@@ -39,7 +39,11 @@ def detect_batch(model, x_pad: torch.Tensor, h: int, w: int, border: int = 15, n
 def detect_batch_u8(model, images_u8: torch.Tensor, border: int = 15, nms_size: int = 15, num_points: int = 1000):
     """Raw uint8 images on the GPU (gray ``[B,H,W]`` or RGB ``[B,H,W,3]``) -> keypoints, nothing on the host:
     normalisation and padding are fused into the first kernels (``MLP_MA_DECODER.forward_u8``), crop/border/NMS/
-    top-K into the last.  Same return values as :func:`detect_batch`."""
+    top-K into the last.  Same return values as :func:`detect_batch`.
+
+    Split-f16 guard: the NMS is enqueued right behind the forward, so under the default ``BALF_FP16_GUARD=lazy`` a batch whose
+    status block turns out flagged has gone through the NMS with the split path's score map; ``model.fp16_guard_check()``
+    returns True then (and repairs ``prob``): repeat the call, or run with ``BALF_FP16_GUARD=sync``."""
     h, w = images_u8.shape[1], images_u8.shape[2]
     _, _, top, left = arch.padded_hw(h, w)
     prob = model.forward_u8(images_u8, want_logits=False)["prob"]
@@ -79,6 +83,9 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+_SHAPES_CHECKED = set()      # (group, world, B, K, device) whose equal-shard precondition has been verified across the group
+
+
 def allgather_keypoints(idx: torch.Tensor, score: torch.Tensor, count: torch.Tensor, group=None, force: bool = False,
                         total: Optional[int] = None):
     """Every rank ends up with the keypoints of the whole batch, in rank order.
@@ -86,8 +93,11 @@ def allgather_keypoints(idx: torch.Tensor, score: torch.Tensor, count: torch.Ten
     ``total`` = the number of images of the whole batch when the ranks hold the UNEQUAL shards of
     :func:`shard_range` (a batch that does not divide by the world size): every rank pads its slab to
     ``ceil(total / world)`` rows (index -1, score 0, count 0), the collective moves equal shapes, and the
-    padding rows are dropped from the result.  Without ``total`` the shards must be equal (the shapes are
-    checked across the group first: ranks that disagree raise instead of hanging inside RCCL).
+    padding rows are dropped from the result.  Without ``total`` the shards must be equal: the FIRST call with a given
+    (group, B, K) checks the shapes across the group with a small collective of its own and a host read, so that ranks that
+    disagree raise instead of hanging inside RCCL; the verdict is cached and every later call with the same shapes is the
+    one slab collective, enqueued without any host synchronisation (a rank that changes its shapes alone afterwards is
+    outside this check, as with any collective).
     A single-rank group returns its inputs untouched unless ``force`` is set (then the collective runs
     anyway: the plumbing check of SURVEY.md 8e on a one-GPU box)."""
     import torch.distributed as dist
@@ -99,14 +109,18 @@ def allgather_keypoints(idx: torch.Tensor, score: torch.Tensor, count: torch.Ten
     b, k = idx.shape
     if total is None:
         rows = b
-        # equal shards are a precondition of all_gather_into_tensor: make a violation an error on every rank
-        mine = torch.tensor([b, k], dtype=torch.int64, device=idx.device)
-        seen = torch.empty(world * 2, dtype=torch.int64, device=idx.device)
-        dist.all_gather_into_tensor(seen, mine, group=group)
-        seen = seen.view(world, 2)
-        if not bool((seen == mine).all()):
-            raise ValueError(f"allgather_keypoints: slab shapes differ across ranks ({seen.tolist()}); pass total= for the "
-                             f"unequal shards of shard_range")
+        key = (id(group) if group is not None else 0, world, b, k, str(idx.device))
+        if key not in _SHAPES_CHECKED:
+            # equal shards are a precondition of all_gather_into_tensor: make a violation an error on every rank (once per
+            # shape: this costs a second collective and a device-to-host read, which the steady state must not pay)
+            mine = torch.tensor([b, k], dtype=torch.int64, device=idx.device)
+            seen = torch.empty(world * 2, dtype=torch.int64, device=idx.device)
+            dist.all_gather_into_tensor(seen, mine, group=group)
+            seen = seen.view(world, 2)
+            if not bool((seen == mine).all()):
+                raise ValueError(f"allgather_keypoints: slab shapes differ across ranks ({seen.tolist()}); pass total= for the "
+                                 f"unequal shards of shard_range")
+            _SHAPES_CHECKED.add(key)
         shard_rows = [b] * world
     else:
         rows = -(-total // world)

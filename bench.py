@@ -23,6 +23,10 @@ Rank 0 prints ONE JSON line.  `value` = images/s over all GPUs; `keypoints_per_s
                 --pmc passes of this script (profiles/rN_pmc.json, newest round); "bound" says which limit the kernel sits at.
   index_match   BASELINE's "NMS index match vs CPU ref": the images of the CPU sample against the oracle.
   cpu_baseline  the CPU oracle (a port of the reference path, oracle/) on a bounded sample, rank 0, N = 1.
+  sustained     the same step back to back for >= 10 s with the clock / package power medians (the 20-step figure is 0.7 s).
+  host_fed      the reference's real calling pattern: uint8 gray images in (pinned) HOST memory -> H2D on a copy stream,
+                double-buffered -> detect_batch_u8 (logits on) -> [B,2K+1] keypoint slabs back in host memory; images/s and
+                the ratio to the resident figure.  Never `value`.
   other_configs the other BASELINE configurations that fit one GPU, a few steps each, every entry with the roofline of ITS
                 dominant kernel (hipEvents of that run; PMC traffic only for the profiled shape) and a CPU baseline on two
                 of its images; `cpu_baseline.batched` is SURVEY 8(d)'s batch-min(B, 8) leg of the oracle at VGA.
@@ -438,6 +442,144 @@ def power_state_under_load(step, dev, seconds=2.5):
             "note": "median of rocm-smi samples while the timed step runs back to back"}
 
 
+def sustained_run(step, dev, images_per_step, seconds=10.0):
+    """The timed step back to back for >= `seconds` (groups of 4 steps, one synchronisation per group), rocm-smi sampled from a
+    thread all the way: the 20-step headline is 0.7 s of a cold-ish package; this is the throughput, clock and power the
+    silicon sustains."""
+    import re
+    import subprocess
+    import threading
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                d = next(iter(json.loads(o[o.index("{"):]).values()))
+                clk = re.search(r"(\d+)", d.get("sclk clock speed:", ""))
+                pw = next((float(v) for k_, v in d.items() if "Power (W)" in k_), None)
+                if clk and pw is not None:
+                    samples.append((int(clk.group(1)), pw))
+            except Exception:          # noqa: BLE001 -- a diagnostic: never fail the bench over it
+                return
+            stop.wait(0.4)
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize(dev)
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize(dev)
+        n += 4
+    dt = time.perf_counter() - t0
+    stop.set()
+    th.join(timeout=6.0)
+    out = {"seconds": dt, "steps": n, "images_per_s": n * images_per_step / dt, "ms_per_step": dt / n * 1e3}
+    if samples:
+        med = lambda v: sorted(v)[len(v) // 2]          # noqa: E731
+        out.update({"sclk_mhz": med([c for c, _ in samples]), "package_power_w": med([p_ for _, p_ in samples]),
+                    "smi_samples": len(samples),
+                    "joule_per_image": med([p_ for _, p_ in samples]) / (n * images_per_step / dt)})
+    return out
+
+
+def host_fed_run(model, dev, gray_u8, k, steps, resident_images_per_s):
+    """End to end from host memory (the reference's caller starts from a host array and ends with host points,
+    /root/reference/balf/utils/train_utils.py:426-434): uint8 gray batches in PINNED host memory -> H2D on a copy stream into one
+    of two device buffers while the previous batch computes -> detect_batch_u8 with the logits ON -> the [B, 2K+1] int32
+    keypoint slab back into pinned host memory.  1 byte per pixel crosses PCIe instead of the 12 of the padded fp32 batch."""
+    b, h, w = gray_u8.shape
+    host_in = [torch.from_numpy(gray_u8).clone().pin_memory() for _ in range(2)]
+    dev_in = [torch.empty((b, h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
+    host_out = [torch.empty((b, 2 * k + 1), dtype=torch.int32).pin_memory() for _ in range(2)]
+    slab = [torch.empty((b, 2 * k + 1), dtype=torch.int32, device=dev) for _ in range(2)]
+    copy_s = torch.cuda.Stream(dev)
+    main_s = torch.cuda.current_stream(dev)
+    ev_in = [torch.cuda.Event() for _ in range(2)]       # H2D of buffer i done
+    ev_free = [torch.cuda.Event() for _ in range(2)]     # the forward that read buffer i is done
+    ev_out = [torch.cuda.Event() for _ in range(2)]      # slab i is in host memory
+
+    def upload(i):
+        with torch.cuda.stream(copy_s):
+            copy_s.wait_event(ev_free[i])
+            dev_in[i].copy_(host_in[i], non_blocking=True)
+            ev_in[i].record(copy_s)
+
+    def compute(i):
+        main_s.wait_event(ev_in[i])
+        out = model.forward_u8(dev_in[i], want_logits=True)
+        ev_free[i].record(main_s)
+        _, _, top_, left_ = arch.padded_hw(h, w)
+        idx, score, count = ops.nms_topk(out["prob"], top_, left_, h, w, 15, 15, k)
+        slab[i][:, :k] = idx
+        slab[i][:, k:2 * k] = score.view(torch.int32)
+        slab[i][:, 2 * k] = count
+        host_out[i].copy_(slab[i], non_blocking=True)
+        ev_out[i].record(main_s)
+        return idx
+
+    def run(n):
+        for i in range(2):
+            ev_free[i].record(main_s)
+        upload(0)
+        consumed = 0
+        for s_ in range(n):
+            i = s_ & 1
+            if s_ + 1 < n:
+                upload(i ^ 1)                         # the next batch crosses PCIe while this one computes
+            if s_ >= 2:
+                ev_out[i].synchronize()               # the host takes slab i (step s_ - 2) before it is overwritten
+                consumed += int(host_out[i][0, 2 * k])
+            last = compute(i)
+        torch.cuda.synchronize(dev)
+        return last, consumed
+    run(3)
+    t0 = time.perf_counter()
+    last, _ = run(steps)
+    dt = time.perf_counter() - t0
+    i_last = (steps - 1) & 1
+    ok = bool(torch.equal(host_out[i_last][:, :k], last.cpu())) and int(host_out[i_last][:, 2 * k].min()) > 0
+    ips = b * steps / dt
+    return {"images_per_s": ips, "ms_per_step": dt / steps * 1e3, "steps": steps, "ratio_to_resident": ips / resident_images_per_s,
+            "logits": True, "h2d_bytes_per_step": int(b * h * w), "d2h_bytes_per_step": int(b * (2 * k + 1) * 4),
+            "slabs_on_host_match_device": ok,
+            "path": "pinned uint8 gray -> H2D (copy stream, 2 buffers) -> balf_forward_u8 (+logits) -> balf_nms_topk -> [B,2K+1] int32 slab -> pinned host"}
+
+
+def natural_match(model, dev):
+    """index_match on the three photographs / poster of tests/golden/natural.npz against the REFERENCE'S OWN outputs recorded there
+    (its extract_detections points and score-map samples; tests/golden/make_golden.py): identical-input NMS parity through the C
+    oracle, end-to-end overlap with the reference's points, score map error on the recorded samples."""
+    from oracle import oracle as O
+    from oracle import c_oracle
+    from tests.golden import cases
+    f = np.load(os.path.join(ROOT, "tests", "golden", "natural.npz"))
+    ident, overlap, err, n_img = True, 1.0, 0.0, 0
+    for name, (k_, border, nms) in cases.NATURAL_CASES.items():
+        im = cases.poster_u8() if name == "poster" else f[name + ".u8"]
+        h_, w_ = im.shape[:2]
+        _, _, top_, left_ = arch.padded_hw(h_, w_)
+        img = torch.from_numpy(np.ascontiguousarray(im)).to(dev)[None]
+        idx, score, count, prob = pipeline.detect_batch_u8(model, img, border, nms, k_)
+        gp = prob[0].cpu().numpy()
+        err = max(err, float(np.abs(gp[::8, ::8] - f[name + ".prob_s8"]).max()))
+        ri, rs, _ = c_oracle.nms_topk(np.ascontiguousarray(gp[top_:top_ + h_, left_:left_ + w_]), border, nms, k_)
+        ri, rs = O.canonical_order(ri.astype(np.int64), rs)
+        n = int(count[0])
+        gi = idx[0, :n].cpu().numpy()
+        ident = ident and n == ri.size and np.array_equal(gi, ri.astype(np.int32))
+        ref = f[name + ".pts"]
+        rset = set((ref[:, 1] * w_ + ref[:, 0]).astype(np.int64).tolist())
+        overlap = min(overlap, len(rset & set(gi.tolist())) / float(len(rset)))
+        n_img += 1
+    return {"images": n_img, "identical_input": bool(ident), "end_to_end_overlap_with_reference_points": overlap,
+            "prob_max_abs_err_on_recorded_samples": err, "source": "tests/golden/natural.npz (the reference's own outputs)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -454,7 +596,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--topk", type=int, default=2000)
-    ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=8,
+                    help="images in the CPU-baseline / index_match sample, spread over the batch's micro-batches (0 = skip)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of the sustained leg (0 = skip)")
+    ap.add_argument("--host-fed-steps", type=int, default=10, help="steps of the host-fed leg (0 = skip)")
     ap.add_argument("--no-single-rank-collective", action="store_true",
                     help="at N = 1 skip the single-rank RCCL group (then the step has no collective)")
     ap.add_argument("--allow-diagnostic-build", action="store_true",
@@ -706,7 +851,11 @@ def main():
         slabs_identical = bool(all(torch.equal(c_[:3], allc[0][:3]) for c_ in allc) and all(int(c_[3]) == 1 for c_ in allc))
         if not slabs_identical:
             raise SystemExit(f"[bench] rank {rank}: the gathered keypoint slabs differ between ranks (or a shard is misplaced)")
-    gpu_sample = tuple(t[:max(args.cpu_images, 1)].clone() for t in out[3])     # this rank's first images
+    # the CPU sample: images spread over the whole batch, so that both micro-batches of the forward are looked at
+    n_cpu = min(max(args.cpu_images, 1), b)
+    cpu_pick = sorted(set(int(round(i * (b - 1) / max(n_cpu - 1, 1))) for i in range(n_cpu)))
+    pick_t = torch.tensor(cpu_pick, device=dev)
+    gpu_sample = tuple(t.index_select(0, pick_t).clone() for t in out[3])
 
     other = None
     other_prec = "fp32" if args.precision == "fp16" else "fp16"
@@ -766,6 +915,16 @@ def main():
             power["note"] += "; joule_per_image = package power / this rank's images per second"
         latency = [single_image_latency(model, dev, hh, ww, kk) for (hh, ww, kk) in ((480, 640, 1000), (1080, 1920, 2000))]
 
+    sustained = host_fed = natural = None
+    if world == 1 and not rehearsal:
+        if args.sustained_seconds > 0:
+            sustained = sustained_run(step, dev, b, args.sustained_seconds)
+            sustained["ratio_to_timed_steps"] = sustained["images_per_s"] / head["images_per_s"]
+        if args.host_fed_steps > 0:
+            host_fed = host_fed_run(model, dev, gray, k, args.host_fed_steps, head["images_per_s"])
+        if args.cpu_images > 0:
+            natural = natural_match(model, dev)
+
     if rank == 0:
         ips = head["images_per_s"]
         nms_bytes = b * (4.0 * h * w + 8.0 * k + 4.0)
@@ -805,15 +964,19 @@ def main():
             "kernels_ms_per_step": head["kernels_ms_per_step"],
             "other_precision": other,
             "other_configs": other_cfgs,
+            "sustained": sustained,
+            "host_fed": host_fed,
             "batch1_latency": latency,
             "power_state_under_load": power,
             "library_build": build_flags,
         }
         if world == 1 and args.cpu_images > 0:
-            n = min(args.cpu_images, b)
-            res["cpu_baseline"], cpu_probs, cpu_dets = cpu_baseline(gray[:n], k, state, args.cpu_threads)
+            res["cpu_baseline"], cpu_probs, cpu_dets = cpu_baseline(gray[cpu_pick], k, state, args.cpu_threads)
+            res["cpu_baseline"]["sample"] = res["cpu_baseline"]["sample"].replace("(the first of the GPU batch)", f"(images {cpu_pick} of the GPU batch)")
             res["index_match"] = index_match(gpu_sample, cpu_probs, cpu_dets, h, w, k, top, left)
             res["index_match"]["precision"] = args.precision
+            res["index_match"]["batch_images"] = cpu_pick
+            res["index_match"]["natural"] = natural
             if other_cfgs is not None:
                 # SURVEY 8(d)'s second CPU leg: the oracle with batch = min(B, 8) images per forward call, at VGA
                 res["cpu_baseline"]["batched"] = cpu_baseline(synthetic_batch(480, 640, 0, 8), 1000, state, args.cpu_threads,

@@ -3,7 +3,7 @@ cfg1 32 x VGA top-1000, cfg2 64 x 720p top-2000 fp32, cfg3/cfg4 1080p shards (32
 Checked per configuration: (i) NMS/top-K of every image is bit-exact against the C oracle run on the very score
 map the GPU produced ("NMS indices bit-exact on identical input"), (ii) the batch is invisible (an image alone gives
 the same bits), (iii) every image yields its K keypoints, (iv) the score map of one image against the CPU oracle at the configuration's
-full size (1088x1920 included) within 1e-4, (v) end-to-end top-K overlap with the oracle's own detections > 0.97."""
+full size (1088x1920 included) within 1e-4, (v) end-to-end top-K overlap with the oracle's own detections >= 0.995 (measured 0.999-1.0)."""
 import os
 import sys
 
@@ -74,7 +74,8 @@ def test_baseline_configuration(name, b, h, w, k, precision, oracle_images):
     # (iv) score map of one image against the CPU oracle (fp32 torch ops) at the configuration's FULL size, north_star
     #      tolerance 1e-4 (the oracle takes ~5 s per 1080p image on the box's host), and (v) the end-to-end keypoint
     #      agreement: GPU score map -> GPU NMS/top-K against oracle score map -> C-oracle NMS/top-K (SURVEY 8d iii:
-    #      1e-5 of score-map noise moves ~0.6 % of the top-K set; the gate leaves room for that and no more)
+    #      1e-5 of score-map noise moves ~0.6 % of the top-K set; the maps here differ by 2-6e-6 and the measured overlap is
+    #      0.999-1.0: the gate is 0.995, so that a regression that moves 1 % of the keypoints fails)
     g = imgs[1].cpu().numpy()
     x = pipeline.pad_batch(synth.gray_to_rgb_norm(g)[None])
     with torch.no_grad():
@@ -84,4 +85,4 @@ def test_baseline_configuration(name, b, h, w, k, precision, oracle_images):
     overlap = len(set(ri.tolist()) & set(idx[1].cpu().numpy().tolist())) / float(k)
     print(f"{name}: score map max-abs err vs oracle {err:.3e}, end-to-end top-{k} overlap {overlap:.4f}")
     assert err < 1e-4, (name, err)
-    assert overlap > 0.97, (name, overlap)
+    assert overlap >= 0.995, (name, overlap)

@@ -69,7 +69,7 @@ def test_f16_split_vga_detections(model16):
     idx, sc, cnt = ops.nms_topk(prob, top, left, h, w, 15, 15, k)
     overlap = np.intersect1d(idx[0].cpu().numpy(), f["vga.idx"]).size / k
     print("f16x3 end-to-end index overlap with the reference:", overlap)
-    assert overlap > 0.97
+    assert overlap >= 0.995, overlap
 
 
 @pytest.mark.parametrize("shape", [(4, 512, 640), (2, 1088, 1920)])
@@ -128,10 +128,10 @@ def test_forward_vga_vs_reference_golden_and_detections(model):
     ri, rs = O.detect_from_prob(p, h, w, 15, 15, k)
     assert int(cnt[0]) == ri.size
     assert np.array_equal(idx[0, :ri.size].cpu().numpy(), ri.astype(np.int32))
-    # end-to-end overlap with the reference's own detections (reported, loosely gated: SURVEY 7.2)
+    # end-to-end overlap with the reference's own detections (measured 0.999-1.0; gate 0.995)
     overlap = np.intersect1d(idx[0].cpu().numpy(), f["vga.idx"]).size / k
     print("end-to-end index overlap with the reference:", overlap)
-    assert overlap > 0.97
+    assert overlap >= 0.995, overlap
 
 
 def test_batch_invariance_and_determinism(model):
@@ -421,6 +421,72 @@ def test_status_block_catches_what_the_load_time_probes_miss(monkeypatch, mode):
     m2(calm)
     with pytest.raises(BalfHipError, match="left the range"):
         m2(xb)
+
+
+def test_lazy_guard_attributes_the_flag_to_its_call_and_holds_no_tensor(monkeypatch):
+    """(a) the host runs ahead -- flagged call A, then calm calls B, C with no synchronisation in between: every call
+    has a status block of its own, so the flag is charged to A (the warning names it and says two later calls were enqueued), A's
+    tensor is repaired, B and C are left alone; (b) the guard keeps weak references only: a flagged batch whose outputs the
+    caller dropped is reported as not repairable and its memory is free again."""
+    import gc
+    import warnings as W
+    from balf_amd.model import get_model
+    sd, bright = _scaled_checkpoint_and_images()
+    monkeypatch.delenv("BALF_FP16_STRICT", raising=False)
+    monkeypatch.setenv("BALF_FP16_GUARD", "lazy")
+    ref = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+    ref.load_state_dict(sd)
+    ref.precision = "fp32"
+    ref = ref.eval().to("cuda:0")
+    calm = cases.forward_input(1, 128, 128, 3).to("cuda:0")
+    xb = bright.to("cuda:0")
+    want_a = ref(xb, want_logits=False)["prob"]
+
+    def fresh():
+        m = get_model.load_model(arch.DEFAULT_MODEL_CFG)
+        m.load_state_dict(sd)
+        m = m.eval().to("cuda:0")
+        with W.catch_warnings():
+            W.simplefilter("error")
+            m(calm)
+        torch.cuda.synchronize()
+        return m
+    # (a)
+    m = fresh()
+    first = m._guard[torch.device("cuda:0")].seq
+    with W.catch_warnings():
+        W.simplefilter("error")
+        out_a = m(xb, want_logits=False)
+        out_b = m(calm, want_logits=False)
+        out_c = m(calm, want_logits=False)
+    b_before = out_b["prob"].clone()
+    with pytest.warns(RuntimeWarning) as rec:
+        assert m.fp16_guard_check(synchronize=True)
+    text = " ".join(str(r.message) for r in rec)
+    assert f"guarded call #{first + 1}" in text and "2 later forward(s)" in text and "same output tensors" in text, text
+    torch.cuda.synchronize()
+    assert torch.equal(out_a["prob"], want_a)
+    assert torch.equal(out_b["prob"], b_before) and torch.equal(out_c["prob"], b_before)
+    assert m.effective_precision == "fp32" and not m._guard[torch.device("cuda:0")].pending
+    # (b)
+    m = fresh()
+    big = xb.repeat(8, 1, 1, 1).contiguous()
+    with W.catch_warnings():
+        W.simplefilter("error")
+        m(calm.repeat(8, 1, 1, 1).contiguous())          # (grows the cached workspace to this batch size first)
+    assert not m.fp16_guard_check(synchronize=True)
+    gc.collect()
+    base = torch.cuda.memory_allocated()
+    with W.catch_warnings():
+        W.simplefilter("error")
+        out = m(big)
+    held = torch.cuda.memory_allocated()
+    assert held - base >= out["prob"].numel() * 4
+    del out
+    gc.collect()
+    assert torch.cuda.memory_allocated() <= base + 4096, "the pending guard entry keeps the dropped outputs alive"
+    with pytest.warns(RuntimeWarning, match="could not be repaired"):
+        assert m.fp16_guard_check(synchronize=True)
 
 
 def test_single_image_callers_repeat_a_flagged_call(monkeypatch):

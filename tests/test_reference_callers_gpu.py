@@ -57,7 +57,7 @@ def test_headline_geometry_vs_reference(models, name, precision):
     gi = (pts[:, 1] * w + pts[:, 0]).astype(np.int64)
     overlap = np.intersect1d(gi, f[name + ".idx"].astype(np.int64)).size / k
     print(name, precision, "top-K overlap with the reference's extract_detections:", overlap)
-    assert overlap > 0.97
+    assert overlap >= 0.995, overlap      # measured 0.999-1.0 (a gate a 2 % regression passes is not a gate)
     assert tuple(score_map.shape) == (1, 1, h, w)
 
 
@@ -90,7 +90,7 @@ def test_extract_detections_end_to_end(models, name, precision):
     assert pts.shape == ref.shape
     gi, ri = (pts[:, 1] * w + pts[:, 0]).astype(np.int64), (ref[:, 1] * w + ref[:, 0]).astype(np.int64)
     overlap = np.intersect1d(gi, ri).size / ri.size
-    assert overlap > 0.97, overlap
+    assert overlap >= 0.995, overlap
     both = np.intersect1d(gi, ri)
     gs = dict(zip(gi.tolist(), pts[:, 3])); rs = dict(zip(ri.tolist(), ref[:, 3]))
     assert max(abs(gs[i] - rs[i]) for i in both.tolist()) < TIGHT
@@ -111,7 +111,7 @@ def test_demo_detect_vs_reference(models, name, precision):
     if args.sub_pixel:
         # same points in the same order (a near-tie flip would show as a > 1 px difference)
         close = (np.abs(res - ref).max(axis=1) < 1e-3).mean()
-        assert close >= 0.98, close
+        assert close >= 0.995, close
     else:
         same = (res == ref).all(axis=1).mean()
-        assert same >= 0.98, same
+        assert same >= 0.995, same
