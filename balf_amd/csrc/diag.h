@@ -44,13 +44,17 @@
 #ifndef BALF_F32_DBG
 #define BALF_F32_DBG 0           // exact-fp32 stage-1 grid kernel (stage1_f32.h) stores intermediate tensor k into U; with BALF_DEBUG_STOP_STAGE set the forward stops there (tests/experiments/f32_s1_debug.py)
 #endif
+#ifndef BALF_ABLATE_UWINDOW
+#define BALF_ABLATE_UWINDOW 0    // stages 1-2: u' (grid kernel's store, block kernel's load) wraps inside a window of this many MiB (a power of two), i.e. stays in the Infinity Cache: the bound of "u' through the cache" (round 6)
+#endif
 #ifndef BALF_S1_STRICT
 #define BALF_S1_STRICT 0         // every hand-placed vmcnt wait of the persistent kernels drains the queue (debugging aid: correct, slow)
 #endif
 
 #define BALF_DIAGNOSTIC_BUILD                                                                                      \
     (BALF_ABLATE_GELU || BALF_ABLATE_BARRIER || BALF_ABLATE_LOADLAT || BALF_ABLATE_LUTCOPY || BALF_ABLATE_WSTREAM || \
-     BALF_ABLATE_SPLIT || BALF_DROP_WLO || BALF_STAMPS || BALF_HN_STAMPS || BALF_S1_STRICT || BALF_DEBUG_STOP || BALF_ABLATE_QSTREAM || BALF_F32_DBG)
+     BALF_ABLATE_SPLIT || BALF_DROP_WLO || BALF_STAMPS || BALF_HN_STAMPS || BALF_S1_STRICT || BALF_DEBUG_STOP || BALF_ABLATE_QSTREAM || BALF_F32_DBG || \
+     BALF_ABLATE_UWINDOW)
 #if BALF_DIAGNOSTIC_BUILD && !defined(BALF_ALLOW_DIAGNOSTIC_BUILD)
 #error "a diagnostic switch (csrc/diag.h) is set: pass -DBALF_ALLOW_DIAGNOSTIC_BUILD=1 as well (tools/build_variant.sh does) -- such a library must not ship"
 #endif
@@ -62,4 +66,4 @@
     BALF_DIAG_ITEM(BALF_ABLATE_GELU) BALF_DIAG_ITEM(BALF_ABLATE_BARRIER) BALF_DIAG_ITEM(BALF_ABLATE_LOADLAT)        \
     BALF_DIAG_ITEM(BALF_ABLATE_LUTCOPY) BALF_DIAG_ITEM(BALF_ABLATE_WSTREAM) BALF_DIAG_ITEM(BALF_ABLATE_SPLIT)       \
     BALF_DIAG_ITEM(BALF_DROP_WLO) BALF_DIAG_ITEM(BALF_STAMPS) BALF_DIAG_ITEM(BALF_HN_STAMPS) BALF_DIAG_ITEM(BALF_S1_STRICT) \
-    BALF_DIAG_ITEM(BALF_DEBUG_STOP) BALF_DIAG_ITEM(BALF_ABLATE_QSTREAM) BALF_DIAG_ITEM(BALF_F32_DBG)
+    BALF_DIAG_ITEM(BALF_DEBUG_STOP) BALF_DIAG_ITEM(BALF_ABLATE_QSTREAM) BALF_DIAG_ITEM(BALF_F32_DBG) BALF_DIAG_ITEM(BALF_ABLATE_UWINDOW)

@@ -88,9 +88,8 @@ __device__ __forceinline__ double make_key(float v, int idx) {
 }
 // maximum of two keys (positive normal doubles or +0) = the unsigned maximum of their bit patterns, in one instruction
 __device__ __forceinline__ double kmax(double x, double y) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
+    asm("v_max_f64 %0, %0, %1" : "+v"(x) : "v"(y));      // ("+v": the repo-wide rule for inline-asm VALU, test_build_invariants.py)
+    return x;
 }
 
 // workgroup barrier that waits for the LDS traffic only: the score values requested for the next tile stay in flight

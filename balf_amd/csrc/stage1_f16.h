@@ -305,6 +305,15 @@ __device__ __forceinline__ void store_frag32(float *base, long pix, int C, int s
     *reinterpret_cast<h8 *>(p + 32) = v.lo;
 }
 
+// BALF_ABLATE_UWINDOW (diag.h): pixel index of u' wrapped into a window of that many MiB (wrong results, timing only)
+__device__ __forceinline__ long uwin_pix(long pix, int C) {
+#if BALF_ABLATE_UWINDOW
+    return pix & ((((long)BALF_ABLATE_UWINDOW << 20) / (C * 4)) - 1);
+#else
+    return pix;
+#endif
+}
+
 // The block kernel stores x1 and the channel sums of the RCAB's hidden layer only; the tail kernel (MODE 2) recomputes the
 // RCAB branch from x1.
 #ifndef BALF_S1_KEEP_X0
@@ -537,8 +546,13 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
 #pragma unroll
                 for (int p = 0; p < P; ++p) { ub[p][0] = load_frag32(A.U, pix0 + p * pstep, C, 0, h); ub[p][1] = load_frag32(A.U, pix0 + p * pstep, C, 1, h); }
             } else {
+#if BALF_ABLATE_UWINDOW
+                const unsigned uoff = (unsigned)uwin_pix((long)g.n * hw + g.y * W + g.x0, 32) * 128u + h * 16u;
+                const char *ubase = uniform_ptr(reinterpret_cast<const char *>(A.U));
+#else
                 const unsigned uoff = (unsigned)(g.y * W + g.x0) * 128u + h * 16u;
                 const char *ubase = uniform_ptr(reinterpret_cast<const char *>(A.U) + (long)g.n * (long)hw * 128);
+#endif
 #define BALF_S1_UB(PI, SI)                                                                                          \
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 offset:%c4\n\tglobal_load_dwordx4 %1, %2, %3 offset:%c5"        \
                  : "=&v"(ub[PI][SI].hi), "=&v"(ub[PI][SI].lo) : "v"(uoff), "s"(ubase), "i"(PI * 128 + SI * 64), "i"(PI * 128 + SI * 64 + 32) : "memory")
@@ -744,8 +758,8 @@ __global__ __launch_bounds__(s1_waves<MODE>() * 64, 1) void stage1_kernel16(Stag
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                store_frag32(A.U, pix0 + p * pstep, C, 0, h, s1_split8(o[p], 0));
-                store_frag32(A.U, pix0 + p * pstep, C, 1, h, s1_split8(o[p], 1));
+                store_frag32(A.U, uwin_pix(pix0 + p * pstep, C), C, 0, h, s1_split8(o[p], 0));
+                store_frag32(A.U, uwin_pix(pix0 + p * pstep, C), C, 1, h, s1_split8(o[p], 1));
             }
             STAMP(9);   // u' store
         } else {

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
                 for (int r = 0; r < 16; ++r) o[rt][r] += z[rt][r];
             STAMP(14);  // split + dense2 + residual
 #pragma unroll
-            for (int s = 0; s < 4; ++s) store_frag32(A.U, pix, C, s, h, s1_split8(o[s >> 1], s & 1));
+            for (int s = 0; s < 4; ++s) store_frag32(A.U, uwin_pix(pix, C), C, s, h, s1_split8(o[s >> 1], s & 1));
             STAMP(15);  // split + u' store
         } else {
             // ---- block branch: RSHMAG.dense2 over cat[u', v'] with its weights streamed from L2 ----
@@ -575,8 +575,13 @@ __global__ __launch_bounds__(s2_waves<MODE>() * 64, 1) void stage2_kernel16(Stag
             // requested after dense2.
             HL ub[4];
             {
+#if BALF_ABLATE_UWINDOW
+                const unsigned uo = (unsigned)uwin_pix((long)g.n * hw + g.y * W + g.x, 64) * 256u + (unsigned)h * 16u;
+                const char *ubase = uniform_ptr(reinterpret_cast<const char *>(A.U));
+#else
                 const unsigned uo = (unsigned)(g.y * W + g.x) * 256u + (unsigned)h * 16u;
                 const char *ubase = uniform_ptr(reinterpret_cast<const char *>(A.U) + (long)g.n * (long)hw * 256);
+#endif
                 asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %8, %9\n\tglobal_load_dwordx4 %1, %8, %9 offset:32\n\t"
                              "global_load_dwordx4 %2, %8, %9 offset:64\n\tglobal_load_dwordx4 %3, %8, %9 offset:96\n\t"
                              "global_load_dwordx4 %4, %8, %9 offset:128\n\tglobal_load_dwordx4 %5, %8, %9 offset:160\n\t"

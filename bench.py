@@ -487,7 +487,7 @@ def sustained_run(step, dev, images_per_step, seconds=10.0):
     return out
 
 
-def host_fed_run(model, dev, gray_u8, k, steps, resident_images_per_s):
+def host_fed_run(model, dev, gray_u8, k, steps, resident_step):
     """End to end from host memory (the reference's caller starts from a host array and ends with host points,
     /root/reference/balf/utils/train_utils.py:426-434): uint8 gray batches in PINNED host memory -> H2D on a copy stream into one
     of two device buffers while the previous batch computes -> detect_batch_u8 with the logits ON -> the [B, 2K+1] int32
@@ -526,7 +526,9 @@ def host_fed_run(model, dev, gray_u8, k, steps, resident_images_per_s):
         for i in range(2):
             ev_free[i].record(main_s)
         upload(0)
+        copy_s.synchronize()                          # steady state: in a continuous feed this upload ran under the previous batch
         consumed = 0
+        t_start[0] = time.perf_counter()
         for s_ in range(n):
             i = s_ & 1
             if s_ + 1 < n:
@@ -537,14 +539,26 @@ def host_fed_run(model, dev, gray_u8, k, steps, resident_images_per_s):
             last = compute(i)
         torch.cuda.synchronize(dev)
         return last, consumed
+
+    def resident(n):                                  # the headline step, timed right before and right after (same thermal state)
+        resident_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            resident_step()
+        torch.cuda.synchronize(dev)
+        return b * n / (time.perf_counter() - t0)
+    t_start = [0.0]
     run(3)
-    t0 = time.perf_counter()
+    res_before = resident(max(steps // 2, 4))
     last, _ = run(steps)
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t_start[0]
     i_last = (steps - 1) & 1
     ok = bool(torch.equal(host_out[i_last][:, :k], last.cpu())) and int(host_out[i_last][:, 2 * k].min()) > 0
     ips = b * steps / dt
-    return {"images_per_s": ips, "ms_per_step": dt / steps * 1e3, "steps": steps, "ratio_to_resident": ips / resident_images_per_s,
+    res_ips = 0.5 * (res_before + resident(max(steps // 2, 4)))
+    return {"images_per_s": ips, "ms_per_step": dt / steps * 1e3, "steps": steps, "ratio_to_resident": ips / res_ips,
+            "resident_images_per_s_adjacent": res_ips,
             "logits": True, "h2d_bytes_per_step": int(b * h * w), "d2h_bytes_per_step": int(b * (2 * k + 1) * 4),
             "slabs_on_host_match_device": ok,
             "path": "pinned uint8 gray -> H2D (copy stream, 2 buffers) -> balf_forward_u8 (+logits) -> balf_nms_topk -> [B,2K+1] int32 slab -> pinned host"}
@@ -599,7 +613,7 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=8,
                     help="images in the CPU-baseline / index_match sample, spread over the batch's micro-batches (0 = skip)")
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of the sustained leg (0 = skip)")
-    ap.add_argument("--host-fed-steps", type=int, default=10, help="steps of the host-fed leg (0 = skip)")
+    ap.add_argument("--host-fed-steps", type=int, default=20, help="steps of the host-fed leg (0 = skip)")
     ap.add_argument("--no-single-rank-collective", action="store_true",
                     help="at N = 1 skip the single-rank RCCL group (then the step has no collective)")
     ap.add_argument("--allow-diagnostic-build", action="store_true",
@@ -707,6 +721,16 @@ def main():
         x_ = torch.zeros((gray_u8.shape[0], 3, hp_, wp_), dtype=torch.float32, device=dev)
         x_[:, :, top_:top_ + hh, left_:left_ + ww] = g[:, None]
         return x_
+
+    # which device and how much workspace every rank really uses (the 8-GPU run binds rank r to cuda:LOCAL_RANK and sizes its own
+    # workspace; the rehearsal puts every rank on cuda:0 and says so)
+    rank_info = {"rank": rank, "local_rank_env": int(os.environ.get("LOCAL_RANK", "0")), "cuda_device": dev.index,
+                 "forward_workspace_bytes": int(_balf_lib.lib().balf_forward_workspace_bytes(b, hp, wp)),
+                 "images": [rank * b, rank * b + b]}
+    rank_devices = [rank_info]
+    if have_group and world > 1:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, rank_info)
 
     # synthetic inputs, resident in HBM before the timed region: this rank's shard of the global batch
     gray = synthetic_batch(h, w, rank * b, b)
@@ -921,7 +945,7 @@ def main():
             sustained = sustained_run(step, dev, b, args.sustained_seconds)
             sustained["ratio_to_timed_steps"] = sustained["images_per_s"] / head["images_per_s"]
         if args.host_fed_steps > 0:
-            host_fed = host_fed_run(model, dev, gray, k, args.host_fed_steps, head["images_per_s"])
+            host_fed = host_fed_run(model, dev, gray, k, args.host_fed_steps, step)
         if args.cpu_images > 0:
             natural = natural_match(model, dev)
 
@@ -944,6 +968,7 @@ def main():
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if have_group else 0,
             "per_rank_images_per_s": per_rank, "allgather_device_us": allgather_us,
             "gathered_slabs_identical": slabs_identical,
+            "rank_devices": rank_devices,
             "rank_env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
             "launched_by": "bench.py" if os.environ.get("BALF_BENCH_LAUNCHED") else
                            ("external launcher" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "direct"),

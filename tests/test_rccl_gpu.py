@@ -124,3 +124,29 @@ def test_two_ranks_on_one_gpu_rehearsal():
     assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["launched_by"] == "bench.py"
     assert res["gathered_slabs_identical"] is True and res["config"]["global_batch"] == 6
     assert res["keypoints_per_image"] == 1000.0 and res["per_rank_images_per_s"]["min"] > 0
+
+
+def test_four_ranks_on_one_gpu_rehearsal_at_the_real_shard():
+    """VERDICT r5 item 6, within what a one-GPU box allows (at most 6 processes may hold the card, and this pytest process is one
+    of them): FOUR ranks, each with the real per-GPU workload of BASELINE configs[3] -- 32 x 1080p, its own 14.8 GB workspace --
+    global batch 128, gloo through host memory.  Every rank verifies inside bench.py that all ranks hold identical gathered slabs
+    with its own shard at its rows; the line lists, per rank, the LOCAL_RANK it was given (the device it binds on a real node),
+    the shard it computed and the workspace it sized.  A rehearsal, never a measurement; the 8-rank form of the launcher runs
+    on the CPU in tests/test_bench_launcher.py."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["BALF_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--other-configs", "0", "--other-steps", "0", "--cpu-images", "0"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["rehearsal"] is True and res["n_gpus"] == 4 and res["rccl_ranks"] == 4
+    assert res["gathered_slabs_identical"] is True and res["config"]["global_batch"] == 128
+    assert res["keypoints_per_image"] == 2000.0
+    devs = res["rank_devices"]
+    assert [d["rank"] for d in devs] == [0, 1, 2, 3] and [d["local_rank_env"] for d in devs] == [0, 1, 2, 3]
+    assert [d["images"] for d in devs] == [[0, 32], [32, 64], [64, 96], [96, 128]]
+    assert all(14.0e9 < d["forward_workspace_bytes"] < 15.5e9 for d in devs), devs

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 export BALF_FP16_CHECK=0      # (the one-off split-f16 range check of a new checkpoint would add three tiny dispatches per kernel to the averages)
 i=0
 for ctrs in "$@"; do
-  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 "$root/bench.py" --steps 1 --warmup 1 --batch-per-gpu $IMAGES --cpu-images 0 --other-steps 0 --other-configs 0 --no-single-rank-collective --precision "$prec" > /dev/null 2>"$out/pass$i.err"
+  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 "$root/bench.py" --steps 1 --warmup 1 --batch-per-gpu $IMAGES --cpu-images 0 --other-steps 0 --other-configs 0 --no-single-rank-collective --sustained-seconds 0 --host-fed-steps 0 --precision "$prec" ${PMC_EXTRA_ARGS:-} > /dev/null 2>"$out/pass$i.err"
   i=$((i+1))
 done
 python3 "$root/tools/pmc_summary.py" "$out" > "$out/summary.txt"
