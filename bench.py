@@ -940,14 +940,23 @@ def main():
         latency = [single_image_latency(model, dev, hh, ww, kk) for (hh, ww, kk) in ((480, 640, 1000), (1080, 1920, 2000))]
 
     sustained = host_fed = natural = None
+    rccl_ranks = dist.get_world_size() if have_group else 0
     if world == 1 and not rehearsal:
         if args.sustained_seconds > 0:
             sustained = sustained_run(step, dev, b, args.sustained_seconds)
             sustained["ratio_to_timed_steps"] = sustained["images_per_s"] / head["images_per_s"]
-        if args.host_fed_steps > 0:
-            host_fed = host_fed_run(model, dev, gray, k, args.host_fed_steps, step)
         if args.cpu_images > 0:
             natural = natural_match(model, dev)
+        if args.host_fed_steps > 0:
+            # a single-GPU leg with one host synchronisation per step: the single-rank RCCL group of the headline step is taken
+            # down first -- while it is alive (torch's NCCL watchdog thread polling the runtime) this host-paced loop, and the
+            # resident step timed beside it, lose ~4 % (measured: ratio 0.948 with the group, 0.986 without)
+            if have_group:
+                dist.barrier()
+                dist.destroy_process_group()
+                have_group = False
+            host_fed = host_fed_run(model, dev, gray, k, args.host_fed_steps, step)
+            host_fed["collective"] = "none (single-GPU leg; the headline's single-rank RCCL group is destroyed before it)"
 
     if rank == 0:
         ips = head["images_per_s"]
@@ -957,7 +966,7 @@ def main():
                  if args.precision == "fp16" else "f32")
         if collective_note is None:
             collective_note = ("all_gather_into_tensor of [B,2K+1] int32 keypoint slabs (RCCL)"
-                               + ("" if world > 1 else ", single-rank group") if have_group else "none")
+                               + ("" if world > 1 else ", single-rank group") if rccl_ranks else "none")
         res = {
             "metric": ("REHEARSAL (ranks share one GPU, gloo): not a measurement" if rehearsal else
                        "images/sec + keypoints/sec on 1080p gray (detector forward + NMS + top-K); NMS index match vs CPU ref"
@@ -965,7 +974,7 @@ def main():
             "rehearsal": rehearsal,
             "value": ips, "unit": "images/s", "keypoints_per_s": ips * kp_per_image,
             "keypoints_per_image": kp_per_image,
-            "n_gpus": world, "rccl_ranks": dist.get_world_size() if have_group else 0,
+            "n_gpus": world, "rccl_ranks": rccl_ranks,
             "per_rank_images_per_s": per_rank, "allgather_device_us": allgather_us,
             "gathered_slabs_identical": slabs_identical,
             "rank_devices": rank_devices,
