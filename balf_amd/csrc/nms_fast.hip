@@ -53,7 +53,7 @@ constexpr int RH_MAX = TH + 2 * GD_MAX;      // 64 region rows
 constexpr int NS = 512;                      // pairwise mode up to this many candidates in the halo region
 constexpr int ROUNDS_DEFAULT = 16;           // rounds enqueued as launches of their own before the per-image tail
 constexpr unsigned KEY_BIAS = 0x00100000u;   // keeps a key's high word out of the double's denormal range
-constexpr int ALIVE_FOREVER = 0x7f7f7f7f;    // dead_round of a tile with candidates (hipMemsetAsync 0x7f)
+constexpr int ALIVE_FOREVER = 0x7f7f7f7f;    // dead_round of a tile with candidates
 
 struct GreedyArgs {
     const float *src;             // [B, Hs, Ws]
@@ -69,6 +69,7 @@ struct GreedyArgs {
     int *ctr;                     // counters, one per 256-byte line (CTR_STRIDE ints): survivors [B], list lengths [2, B], dlist length [B]
     int2 *surv;                   // [B, H * W] kept points (flat index, score bits), appended as they are kept
     int *counts;                  // [B] survivors per image, contiguous (written by the tail kernel for the top-K kernel)
+    int32_t *total;               // [B] the caller's copy of it (may be null)
 };
 // every counter is hit by one atomic per tile and round: each gets a cache line (and so an L2 channel) of its own -- with
 // the 32 images' counters in one 128-byte line the first kill pass spent 0.4 ms queueing on that line
@@ -582,7 +583,11 @@ __global__ __launch_bounds__(KTHREADS) void greedy_tail_kernel(GreedyArgs a, int
         __syncthreads();
         __threadfence();
     }
-    if (threadIdx.x == 0) a.counts[b] = __hip_atomic_load(ctr_surv(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        const int n = __hip_atomic_load(ctr_surv(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.counts[b] = n;
+        if (a.total) a.total[b] = n;
+    }
 }
 
 // soft_argmax_points (test_utils.py:170-215) on the selected points: the patch is normalised by its sum + 1e-6,
@@ -681,10 +686,10 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
                  reinterpret_cast<u64 *>(w + l.off_alive), reinterpret_cast<u64 *>(w + l.off_kept),
                  reinterpret_cast<int *>(w + l.off_dead), reinterpret_cast<int *>(w + l.off_list),
                  reinterpret_cast<int *>(w + l.off_dlist), reinterpret_cast<int *>(w),
-                 reinterpret_cast<int2 *>(w + l.off_surv), reinterpret_cast<int *>(w + l.off_counts)};
-    if (hipMemsetAsync(w, 0, l.zero_bytes, st) != hipSuccess) return BALF_ERR_LAUNCH;
-    if (hipMemsetAsync(w + l.off_dead, 0x7f, l.dead_bytes, st) != hipSuccess) return BALF_ERR_LAUNCH;   // ALIVE_FOREVER
-    static_assert(ALIVE_FOREVER == 0x7f7f7f7f, "dead_round is initialised by a byte memset");
+                 reinterpret_cast<int2 *>(w + l.off_surv), reinterpret_cast<int *>(w + l.off_counts), total_dev};
+    // (fill kernels, not hipMemsetAsync: see balf_fill_u32 in common.h)
+    if (balf_fill_u32(w, 0u, l.zero_bytes / 4, st) != BALF_OK) return BALF_ERR_LAUNCH;
+    if (balf_fill_u32(w + l.off_dead, (unsigned)ALIVE_FOREVER, l.dead_bytes / 4, st) != BALF_OK) return BALF_ERR_LAUNCH;
 
     constexpr int keep_lds = (int)sizeof(KeepLds), tail_lds = (int)(sizeof(KeepLds) + sizeof(KillLds));
     static_assert(sizeof(KeepLds) % 16 == 0 && 2 * sizeof(KeepLds) <= 160 * 1024, "two window-mode workgroups per CU");
@@ -715,8 +720,6 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
     BALF_PROF(balf_prof::kGreedyKill, st,
               hipLaunchKernelGGL(greedy_tail_kernel, dim3(B), dim3(KTHREADS), tail_lds, st, a, rounds + 1));
     BALF_LAUNCH_CHECK();
-    if (total_dev && hipMemcpyAsync(total_dev, a.counts, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return BALF_ERR_LAUNCH;
     // the K best kept points by score, sorted (score desc, index asc); count_dev = rows returned (<= K)
     int rc = balf_topk_select_launch(a.surv, a.counts, (long)H * W, B, K, /*zero_fallback=*/0, idx_dev, score_dev,
                                      count_dev, st, /*thr_explicit=*/0u);

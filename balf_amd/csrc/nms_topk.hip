@@ -637,6 +637,21 @@ int next_pow2(int v) {
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void fill_u32_kernel(unsigned *dst, unsigned value, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = value;
+}
+}  // namespace
+
+int balf_fill_u32(void *dst_dev, unsigned value, size_t n_words, hipStream_t stream) {
+    if (n_words == 0) return BALF_OK;
+    const size_t blocks = (n_words + 255) / 256;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream,
+                       static_cast<unsigned *>(dst_dev), value, n_words);
+    BALF_LAUNCH_CHECK();
+    return BALF_OK;
+}
+
 // shared by balf_nms_topk and balf_greedy_nms (nms_fast.hip)
 int balf_topk_select_launch(const int2 *surv, const int *counts, long cap, int B, int K, int zero_fallback,
                             int32_t *idx_dev, float *score_dev, int32_t *count_dev, hipStream_t st,
@@ -685,8 +700,7 @@ int nms_select(const float *prob_dev, int B, int Hp, int Wp, int crop_y, int cro
     int *counts = reinterpret_cast<int *>(workspace_dev);
     int2 *surv = reinterpret_cast<int2 *>(reinterpret_cast<char *>(workspace_dev) +
                                           balf_align_up((size_t)B * sizeof(int), 256));
-    if (hipMemsetAsync(counts, 0, balf_align_up((size_t)B * sizeof(int), 256), st) != hipSuccess)
-        return BALF_ERR_LAUNCH;
+    if (balf_fill_u32(counts, 0u, balf_align_up((size_t)B * sizeof(int), 256) / 4, st) != BALF_OK) return BALF_ERR_LAUNCH;
     NmsArgs a{prob_dev, Hp, Wp, crop_y, crop_x, H, W, border, nms_size, surv, counts, (long)H * W, nullptr};
     int rc = launch_nms_tiles(a, B, st);
     if (rc != BALF_OK) return rc;

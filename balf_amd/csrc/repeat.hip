@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void rep_count_kernel(const double *src, int n
 
 // off[i] = sum_{k<i} cnt[k]; totals = {sum cnt_s, sum cnt_m, sum poss}
 __global__ __launch_bounds__(1024) void rep_scan_kernel(const int *cnt_s, const int *cnt_m, const int *poss, int ns,
-                                                        int *off_s, int *off_m, int *totals) {
+                                                        int *off_s, int *off_m, int *totals, int *poss_out) {
     __shared__ int wsum[3][16];
     __shared__ int base[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(1024) void rep_scan_kernel(const int *cnt_s, const 
         if (tid == 1023) { base[0] = incl[0]; base[1] = incl[1]; base[2] = incl[2]; }
         __syncthreads();
     }
-    if (tid == 0) { totals[0] = base[0]; totals[1] = base[1]; totals[2] = base[2]; }
+    if (tid == 0) { totals[0] = base[0]; totals[1] = base[1]; totals[2] = base[2]; *poss_out = base[2]; }
 }
 
 __global__ __launch_bounds__(64) void rep_fill_kernel(const double *src, int ns, const double *dst, int nd, RepParams p,
@@ -311,7 +311,7 @@ extern "C" int balf_repeatability(const double *src_dev, int ns, const double *d
     const RepParams p{1.0 - overlap_err, eps, dist_match_thresh, radius_size, 4.0 * radius_size};
     rep_count_kernel<<<ns, 256, 0, st>>>(src_dev, ns, dst_dev, nd, p, w.cnt_s, w.cnt_m, w.poss);
     BALF_LAUNCH_CHECK();
-    rep_scan_kernel<<<1, 1024, 0, st>>>(w.cnt_s, w.cnt_m, w.poss, ns, w.off_s, w.off_m, w.totals);
+    rep_scan_kernel<<<1, 1024, 0, st>>>(w.cnt_s, w.cnt_m, w.poss, ns, w.off_s, w.off_m, w.totals, counts_dev + 2);
     BALF_LAUNCH_CHECK();
     // the list lengths stay on the device (round 5 read them back behind a hipStreamSynchronize): the fill pass cuts a list
     // at max_edges, the sort and assignment kernels read the length themselves
@@ -327,7 +327,6 @@ extern "C" int balf_repeatability(const double *src_dev, int ns, const double *d
                                             errors_dev + which, which ? corr_m_dev : corr_s_dev, cap);
         BALF_LAUNCH_CHECK();
     }
-    if (hipMemcpyAsync(counts_dev + 2, w.totals + 2, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return BALF_ERR_LAUNCH;
     return BALF_OK;
 }
 

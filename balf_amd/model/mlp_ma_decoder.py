@@ -269,8 +269,9 @@ class MLP_MA_DECODER(nn.Module):
         the HIP library, ~2.5x slower) and the module says so -- or raises with BALF_FP16_STRICT=1.  The requested
         precision is left alone: the next checkpoint is judged afresh."""
         g = self._guard.get(device)
-        if g is not None and g.pending and not getattr(self, "_validating", False):
-            self._guard_look(g, final=False)                     # lazy look at the finished calls' status blocks (no wait)
+        if g is not None and g.pending and not getattr(self, "_validating", False) and not torch.cuda.is_current_stream_capturing():
+            self._guard_look(g, final=False)                     # lazy look at the finished calls' status blocks (no wait;
+            #                                                      not under graph capture: an event query would invalidate it)
         wkey = self._weights_key(device)
         prec = self.precision
         if prec == "fp16" and not getattr(self, "_validating", False) and self._fp16_verdict is not None \
@@ -358,7 +359,9 @@ class MLP_MA_DECODER(nn.Module):
         the call and says how many later ones had been enqueued -- repeat those, or run with BALF_FP16_GUARD=sync where that
         matters.  Only weak references are kept: outputs the caller has dropped are not repaired (and not kept alive)."""
         mode = _guard_mode()
-        if prec != "fp16" or mode == "off" or getattr(self, "_validating", False):
+        if prec != "fp16" or mode == "off" or getattr(self, "_validating", False) or torch.cuda.is_current_stream_capturing():
+            # (under hipGraph capture -- torch.cuda.graph -- the call is recorded without a status block: events of a capture cannot
+            # be queried and a replay has no host side that could look; validate such a pipeline once with validate_fp16)
             self._launch(kind, dims, blob, prec, None, *tensors)
             return
         g = self._guard.get(dev)
