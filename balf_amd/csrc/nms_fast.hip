@@ -25,7 +25,7 @@
 //               survivor list, the tile to the next round's list (or dead_round = round).
 //     A neighbour tile that was already dead when the round began is never read (dead_round < round): its words are stale.
 //   * the number of rounds is data dependent (4-8 on score maps, ~W/d on a monotone ramp).  `rounds_launched` rounds are
-//     always enqueued; a launch whose image list is empty returns at once.  What is still alive after them is finished by
+//     always enqueued (12); a launch whose image list is empty returns at once.  What is still alive after them is finished by
 //     greedy_tail_kernel: ONE workgroup per image looping rounds over its own list until the list is empty -- images are
 //     independent, so no workgroup ever waits for another one and every wave reaches its exit.
 // Then the top-K / sort kernel of nms_topk.hip and the optional sub-pixel soft-argmax.
@@ -51,7 +51,7 @@ constexpr int LTHREADS = 64;                 // kill kernel: one wave per tile
 constexpr int RS = TW + 2 * GD_MAX + 1;      // LDS row stride in keys: 97 = 194 dwords = 2 mod 64 -> a column of keys is conflict-free
 constexpr int RH_MAX = TH + 2 * GD_MAX;      // 64 region rows
 constexpr int NS = 512;                      // pairwise mode up to this many candidates in the halo region
-constexpr int ROUNDS_DEFAULT = 16;           // rounds enqueued as launches of their own before the per-image tail
+constexpr int ROUNDS_DEFAULT = 12;           // rounds enqueued as launches of their own before the per-image tail (score maps need 7-9)
 constexpr unsigned KEY_BIAS = 0x00100000u;   // keeps a key's high word out of the double's denormal range
 constexpr int ALIVE_FOREVER = 0x7f7f7f7f;    // dead_round of a tile with candidates
 
@@ -709,12 +709,15 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
     BALF_LAUNCH_CHECK();
     const int rounds = rounds_launched();
     for (int r = 2; r <= rounds; ++r) {
+        // the lists shrink by a factor of 2-4 per round on a score map: later rounds get smaller grids (the workgroups stride over
+        // the list, so a long list -- a ramp -- is still covered; an empty launch of the full grid costs 4.7 us, of 1/16 of it 2)
+        const int gr = r <= 3 ? g1 : (r <= 6 ? (g1 + 3) / 4 : (g1 + 15) / 16);
         BALF_PROF(balf_prof::kGreedyKeep, st,
-                  hipLaunchKernelGGL(greedy_keep_sparse_kernel, dim3(g1, B), dim3(LTHREADS), 0, st, a, r));
+                  hipLaunchKernelGGL(greedy_keep_sparse_kernel, dim3(gr, B), dim3(LTHREADS), 0, st, a, r));
         BALF_PROF(balf_prof::kGreedyKeep, st,
                   hipLaunchKernelGGL(greedy_keep_window_kernel, dim3(gw, B), dim3(KTHREADS), keep_lds, st, a, r));
         BALF_PROF(balf_prof::kGreedyKill, st,
-                  hipLaunchKernelGGL(greedy_kill_kernel<false>, dim3(g1, B), dim3(LTHREADS), 0, st, a, r));
+                  hipLaunchKernelGGL(greedy_kill_kernel<false>, dim3(gr, B), dim3(LTHREADS), 0, st, a, r));
     }
     BALF_LAUNCH_CHECK();
     BALF_PROF(balf_prof::kGreedyKill, st,

@@ -47,7 +47,7 @@ def main():
                       "device_ms_by_slot": {k: round(v[0], 4) for k, v in prof.items()},
                       "launches_by_slot": {k: v[1] for k, v in prof.items()},
                       "candidate_fraction": cand, "kept_per_image": float(out[4].float().mean()),
-                      "rounds_env": os.environ.get("BALF_GREEDY_ROUNDS", "default 16")}))
+                      "rounds_env": os.environ.get("BALF_GREEDY_ROUNDS", "default 12")}))
 
 
 if __name__ == "__main__":
