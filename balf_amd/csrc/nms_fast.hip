@@ -24,10 +24,14 @@
 //       kill -- window OR of the kept bits as shifts of one 128-bit row word, alive &= ~that, kept points appended to the
 //               survivor list, the tile to the next round's list (or dead_round = round).
 //     A neighbour tile that was already dead when the round began is never read (dead_round < round): its words are stale.
+//     A pass is SKIPPED for a tile with nothing to do: keep when no alive bit of its 3 x 3 tile neighbourhood changed in the
+//     previous round (chg_round), kill when no point of that neighbourhood was kept in this one (kept_round) -- see nbr_round_is.
 //   * the number of rounds is data dependent (4-8 on score maps, ~W/d on a monotone ramp).  `rounds_launched` rounds are
 //     always enqueued (12); a launch whose image list is empty returns at once.  What is still alive after them is finished by
 //     greedy_tail_kernel: ONE workgroup per image looping rounds over its own list until the list is empty -- images are
-//     independent, so no workgroup ever waits for another one and every wave reaches its exit.
+//     independent, so no workgroup ever waits for another one and every wave reaches its exit.  The adversarial inputs (a
+//     1080p monotone ramp or constant plateau: ~120-190 rounds with a wavefront of kept points) take 0.2 s there instead
+//     of 1.3 ms, exact like everything else (tools/greedy_ramp_probe.py).
 // Then the top-K / sort kernel of nms_topk.hip and the optional sub-pixel soft-argmax.
 #include <stdlib.h>
 
@@ -64,6 +68,8 @@ struct GreedyArgs {
     u64 *alive;                   // [B, H, ntx]
     u64 *kept;                    // [B, H, ntx] kept in the current round
     int *dead_round;              // [B, nty * ntx]
+    int *chg_round;               // [B, nty * ntx] last round in which the kill pass changed the tile's alive bits (0: never)
+    int *kept_round;              // [B, nty * ntx] last round in which the keep pass kept a point of the tile (0: never)
     int *list;                    // [2, B, nty * ntx] live tiles: list[r & 1] is read by round r, written by round r - 1
     int *dlist;                   // [B, nty * ntx] live tiles of the current round with > NS candidates around them (window mode)
     int *ctr;                     // counters, one per 256-byte line (CTR_STRIDE ints): survivors [B], list lengths [2, B], dlist length [B]
@@ -166,6 +172,33 @@ __device__ __forceinline__ bool tile_dead(const GreedyArgs &a, int b, int tyi, i
     return a.dead_round[((long)b * a.nty + tyi) * a.ntx + txi] < round;
 }
 
+// Activity of a tile's 3 x 3 tile neighbourhood (a halo reaches the adjacent tiles only): did any of them record `value` in `arr`?
+// keep pass of round r: chg_round == r - 1 -- if no alive bit of the neighbourhood changed in the previous round, the tile's
+// candidates and everything around them are what they were when the tile last kept nothing (had it kept a point, its own bits
+// would have changed), so it keeps nothing now either and its kept words are still zero: the pass is skipped.  kill pass of
+// round r: kept_round == r -- no newly kept point in reach, nothing dies.  On a monotone ramp or a plateau (one wavefront of
+// kept points moving one window per round, ~W/d rounds) all but the tiles on the front skip.  Every thread evaluates it alike.
+__device__ __forceinline__ bool nbr_round_is(const GreedyArgs &a, const int *arr, int b, int tyi, int txi, int value) {
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int y = tyi - 1 + k / 3, x = txi - 1 + k % 3;
+        if (y >= 0 && y < a.nty && x >= 0 && x < a.ntx) hit |= arr[((long)b * a.nty + y) * a.ntx + x] == value;
+    }
+    return hit;
+}
+
+// the same for a workgroup that is ONE wave (pairwise keep, kill kernels): lanes 0..8 look at one neighbour each
+__device__ __forceinline__ bool nbr_round_is_wave(const GreedyArgs &a, const int *arr, int b, int tyi, int txi, int value) {
+    const int lane = threadIdx.x;
+    bool hit = false;
+    if (lane < 9) {
+        const int y = tyi - 1 + lane / 3, x = txi - 1 + lane % 3;
+        if (y >= 0 && y < a.nty && x >= 0 && x < a.ntx) hit = arr[((long)b * a.nty + y) * a.ntx + x] == value;
+    }
+    return __ballot(hit) != 0ull;
+}
+
 // The two window passes over the keys in s.in (tile + d halo) and the kept / alive bits of the tile's rows into s.kbits /
 // s.abits (zeroed by the caller before the barrier this begins with).
 template <bool FIRST>
@@ -197,9 +230,10 @@ __device__ __forceinline__ void window_passes(const GreedyArgs &a, KeepLds &s, i
 
 // Keep pass of one tile in rounds >= 2 (window-mode kernel and tail): writes the tile's words of the `kept` map.  All
 // threads of the workgroup take part (blockDim.x a multiple of 64).
-__device__ void keep_tile(const GreedyArgs &a, KeepLds &s, int b, int tile, int round) {
+__device__ void keep_tile(const GreedyArgs &a, KeepLds &s, int b, int tile, int round, bool check_activity) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
+    if (check_activity && !nbr_round_is(a, a.chg_round, b, tyi, txi, round - 1)) return;      // uniform
     const int ty0 = tyi * TH, tx0 = txi * TW;
     const int d = a.d, RH = TH + 2 * d, RW = TW + 2 * d;
     const int ry0 = ty0 - d, rx0 = tx0 - d;
@@ -269,9 +303,13 @@ __device__ void keep_tile(const GreedyArgs &a, KeepLds &s, int b, int tile, int 
         }
     }
     __syncthreads();
-    if (tid < TH && ty0 + tid < a.H) {
-        const long wi = ((long)b * a.H + ty0 + tid) * a.ntx + txi;
-        a.kept[wi] = (u64)s.kbits[tid * 2] | ((u64)s.kbits[tid * 2 + 1] << 32);
+    if (tid < 64) {                                    // wave 0: the tile's 32 row words
+        u64 kw = 0ull;
+        if (tid < TH && ty0 + tid < a.H) {
+            kw = (u64)s.kbits[tid * 2] | ((u64)s.kbits[tid * 2 + 1] << 32);
+            a.kept[((long)b * a.H + ty0 + tid) * a.ntx + txi] = kw;
+        }
+        if (__ballot(kw != 0ull) != 0ull && tid == 0) a.kept_round[(long)b * a.nty * a.ntx + tile] = round;
     }
 }
 
@@ -292,9 +330,16 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 }
 
 // Kill pass of one tile.  Wave 0 of the workgroup does the work; every thread must call it (two barriers).
-__device__ void kill_tile(const GreedyArgs &a, KillLds &s, int b, int tile, int round) {
+__device__ void kill_tile(const GreedyArgs &a, KillLds &s, int b, int tile, int round, bool check_activity) {
     const int tid = threadIdx.x;
     const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
+    if (check_activity && !nbr_round_is(a, a.kept_round, b, tyi, txi, round)) {       // uniform: no newly kept point in reach
+        if (tid == 0) {                                                                // -> the tile lives on unchanged
+            const int nxt = (round + 1) & 1;
+            a.list[((long)nxt * a.B + b) * a.nty * a.ntx + atomicAdd(ctr_list(a, nxt, b), 1)] = tile;
+        }
+        return;
+    }
     const int ty0 = tyi * TH, tx0 = txi * TW;
     const int d = a.d, w = 2 * d + 1, RH = TH + 2 * d;
     const float *img = a.src + (long)b * a.Hs * a.Ws;
@@ -357,7 +402,9 @@ __device__ void kill_tile(const GreedyArgs &a, KillLds &s, int b, int tile, int 
     const u64 na = al & ~v;                            // the kept ones themselves and whoever they suppress
     if (na != al) a.alive[((long)b * a.H + ty0 + tid) * a.ntx + txi] = na;
     const int alive = wave_sum(__popcll(na));
+    const bool changed = __ballot(na != al) != 0ull;
     if (tid == 0) {
+        if (changed) a.chg_round[(long)b * a.nty * a.ntx + tile] = round;
         if (alive == 0) {
             a.dead_round[(long)b * a.nty * a.ntx + tile] = round;
         } else {
@@ -378,6 +425,7 @@ __device__ void keep_tile_sparse(const GreedyArgs &a, SparseLds &s, int b, int t
     const int ty0 = tyi * TH, tx0 = txi * TW;
     const int d = a.d, RH = TH + 2 * d, ry0 = ty0 - d;
     const float *img = a.src + (long)b * a.Hs * a.Ws;
+    if (!nbr_round_is_wave(a, a.chg_round, b, tyi, txi, round - 1)) return;      // nothing around the tile changed: see nbr_round_is
     __syncthreads();
     u64 wv[3] = {0ull, 0ull, 0ull};                   // words lane, lane + 64, lane + 128 of the RH x 3 region words
     if (lane < 9) s.dead[lane] = tile_dead(a, b, tyi - 1 + lane / 3, txi - 1 + lane % 3, round);
@@ -456,8 +504,12 @@ __device__ void keep_tile_sparse(const GreedyArgs &a, SparseLds &s, int b, int t
         if (keep) atomicOr(&s.kbits[(p.y - ty0) * 2 + ((p.x - tx0) >> 5)], 1u << ((p.x - tx0) & 31));
     }
     __syncthreads();
-    if (lane < TH && ty0 + lane < a.H)
-        a.kept[((long)b * a.H + ty0 + lane) * a.ntx + txi] = (u64)s.kbits[lane * 2] | ((u64)s.kbits[lane * 2 + 1] << 32);
+    u64 kw = 0ull;
+    if (lane < TH && ty0 + lane < a.H) {
+        kw = (u64)s.kbits[lane * 2] | ((u64)s.kbits[lane * 2 + 1] << 32);
+        a.kept[((long)b * a.H + ty0 + lane) * a.ntx + txi] = kw;
+    }
+    if (__ballot(kw != 0ull) != 0ull && lane == 0) a.kept_round[(long)b * a.nty * a.ntx + tile] = round;
 }
 
 // Round 1: every tile, candidates straight from the score map (crop, border, threshold in the load), window mode.
@@ -516,10 +568,15 @@ __global__ __launch_bounds__(KTHREADS) void greedy_keep_first_kernel(GreedyArgs 
         if (g + 1 < g1) first_fetch(a, g + 1, v);     // in flight during the passes
         window_passes<true>(a, s, tyi, txi);
         lds_barrier();
-        if (tid < TH && tyi * TH + tid < a.H) {
-            const long wi = ((long)b * a.H + tyi * TH + tid) * a.ntx + txi;
-            a.kept[wi] = (u64)s.kbits[tid * 2] | ((u64)s.kbits[tid * 2 + 1] << 32);
-            a.alive[wi] = (u64)s.abits[tid * 2] | ((u64)s.abits[tid * 2 + 1] << 32);
+        if (tid < 64) {
+            u64 kw = 0ull;
+            if (tid < TH && tyi * TH + tid < a.H) {
+                const long wi = ((long)b * a.H + tyi * TH + tid) * a.ntx + txi;
+                kw = (u64)s.kbits[tid * 2] | ((u64)s.kbits[tid * 2 + 1] << 32);
+                a.kept[wi] = kw;
+                a.alive[wi] = (u64)s.abits[tid * 2] | ((u64)s.abits[tid * 2 + 1] << 32);
+            }
+            if (__ballot(kw != 0ull) != 0ull && tid == 0) a.kept_round[(long)b * tiles + tile] = 1;
         }
     }
 }
@@ -541,7 +598,7 @@ __global__ __launch_bounds__(KTHREADS) void greedy_keep_window_kernel(GreedyArgs
     const int b = blockIdx.y, tiles = a.nty * a.ntx;
     const int n = *ctr_dlist(a, b);
     const int *list = a.dlist + (long)b * tiles;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) keep_tile(a, s, b, list[i], round);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) keep_tile(a, s, b, list[i], round, false);    // (listed by the pairwise kernel: active)
 }
 
 template <bool FIRST>
@@ -549,41 +606,82 @@ __global__ __launch_bounds__(LTHREADS) void greedy_kill_kernel(GreedyArgs a, int
     __shared__ KillLds s;
     const int b = blockIdx.y, tiles = a.nty * a.ntx;
     if (FIRST) {
-        for (int t = blockIdx.x; t < tiles; t += gridDim.x) kill_tile(a, s, b, t, round);
+        for (int t = blockIdx.x; t < tiles; t += gridDim.x) kill_tile(a, s, b, t, round, false);
         return;
     }
     const int cur = round & 1;
     const int n = *ctr_list(a, cur, b);
     if (blockIdx.x == 0 && threadIdx.x == 0) *ctr_dlist(a, b) = 0;                 // the window-mode list of the next round
     const int *list = a.list + ((long)cur * a.B + b) * tiles;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) kill_tile(a, s, b, list[i], round);
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int tile = list[i], tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
+        if (nbr_round_is_wave(a, a.kept_round, b, tyi, txi, round)) {
+            kill_tile(a, s, b, tile, round, false);
+        } else if (threadIdx.x == 0) {                 // no newly kept point in reach: the tile lives on unchanged
+            const int nxt = (round + 1) & 1;
+            a.list[((long)nxt * a.B + b) * tiles + atomicAdd(ctr_list(a, nxt, b), 1)] = tile;
+        }
+    }
 }
 
 // Whatever the enqueued rounds left alive: one workgroup per image runs further rounds over the image's own tile list.
 // The workgroup reads what it wrote itself in the previous pass (bit maps, lists, dead_round): device-scope fences around
 // the barriers, the counters through atomic loads.  Always launched: it also hands the survivor count to the top-K kernel.
+struct TailLds {
+    int act[KTHREADS];             // the listed tiles of the current chunk that have something to do
+    int nact, pad_[3];
+};
+
 __global__ __launch_bounds__(KTHREADS) void greedy_tail_kernel(GreedyArgs a, int round0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KeepLds &sk = *reinterpret_cast<KeepLds *>(smem);
     KillLds &sl = *reinterpret_cast<KillLds *>(smem + sizeof(KeepLds));
-    const int b = blockIdx.x, tiles = a.nty * a.ntx;
+    TailLds &st = *reinterpret_cast<TailLds *>(smem + sizeof(KeepLds) + sizeof(KillLds));
+    const int b = blockIdx.x, tiles = a.nty * a.ntx, tid = threadIdx.x;
     for (int round = round0;; ++round) {
         const int cur = round & 1;
         const int n = __hip_atomic_load(ctr_list(a, cur, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n == 0) break;                                    // uniform: every thread reads the same settled word
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(ctr_list(a, cur ^ 1, b), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(ctr_list(a, cur ^ 1, b), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int *list = a.list + ((long)cur * a.B + b) * tiles;
-        for (int i = 0; i < n; ++i) keep_tile(a, sk, b, list[i], round);
+        int *next = a.list + ((long)(cur ^ 1) * a.B + b) * tiles;
+        // The list is walked in chunks of one tile per thread: every thread decides for ITS tile whether the pass has anything to
+        // do there (nbr_round_is), the tiles that do are collected in LDS and worked off one after the other by the whole
+        // workgroup.  On a ramp or a plateau -- the inputs that reach this kernel with long lists -- that is the wavefront only.
+        for (int base = 0; base < n; base += KTHREADS) {      // keep pass
+            __syncthreads();
+            if (tid == 0) st.nact = 0;
+            __syncthreads();
+            if (base + tid < n) {
+                const int tile = list[base + tid], tyi = tile / a.ntx;
+                if (nbr_round_is(a, a.chg_round, b, tyi, tile - tyi * a.ntx, round - 1)) st.act[atomicAdd(&st.nact, 1)] = tile;
+            }
+            __syncthreads();
+            const int m = st.nact;
+            for (int j = 0; j < m; ++j) keep_tile(a, sk, b, st.act[j], round, false);
+        }
         __threadfence();
         __syncthreads();
         __threadfence();
-        for (int i = 0; i < n; ++i) kill_tile(a, sl, b, list[i], round);
+        for (int base = 0; base < n; base += KTHREADS) {      // kill pass
+            __syncthreads();
+            if (tid == 0) st.nact = 0;
+            __syncthreads();
+            if (base + tid < n) {
+                const int tile = list[base + tid], tyi = tile / a.ntx;
+                if (nbr_round_is(a, a.kept_round, b, tyi, tile - tyi * a.ntx, round)) st.act[atomicAdd(&st.nact, 1)] = tile;
+                else next[atomicAdd(ctr_list(a, cur ^ 1, b), 1)] = tile;          // no newly kept point in reach: lives on unchanged
+            }
+            __syncthreads();
+            const int m = st.nact;
+            for (int j = 0; j < m; ++j) kill_tile(a, sl, b, st.act[j], round, false);
+        }
         __threadfence();
         __syncthreads();
         __threadfence();
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         const int n = __hip_atomic_load(ctr_surv(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.counts[b] = n;
         if (a.total) a.total[b] = n;
@@ -618,15 +716,17 @@ __global__ void subpixel_kernel(GreedyArgs a, const int32_t *idx, const int32_t 
 
 struct Layout {
     size_t zero_bytes;            // the counters (one line each) + counts [B]: cleared per call
-    size_t off_counts, off_dead, dead_bytes, off_list, off_dlist, off_alive, off_kept, off_surv, total;
+    size_t off_counts, off_chg, off_keptr, off_dead, dead_bytes, off_list, off_dlist, off_alive, off_kept, off_surv, total;
 };
 Layout layout(int B, int H, int W) {
     const size_t ntx = balf_ceil_div(W, TW), nty = balf_ceil_div(H, TH), tiles = ntx * nty;
     Layout l;
     l.off_counts = (size_t)4 * B * CTR_STRIDE * sizeof(int);
-    l.zero_bytes = l.off_counts + balf_align_up((size_t)B * sizeof(int), 256);
-    l.off_dead = l.zero_bytes;
     l.dead_bytes = balf_align_up((size_t)B * tiles * sizeof(int), 256);
+    l.off_chg = l.off_counts + balf_align_up((size_t)B * sizeof(int), 256);
+    l.off_keptr = l.off_chg + l.dead_bytes;
+    l.zero_bytes = l.off_keptr + l.dead_bytes;
+    l.off_dead = l.zero_bytes;
     l.off_list = l.off_dead + l.dead_bytes;
     l.off_dlist = l.off_list + balf_align_up((size_t)2 * B * tiles * sizeof(int), 256);
     l.off_alive = l.off_dlist + balf_align_up((size_t)B * tiles * sizeof(int), 256);
@@ -684,14 +784,15 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
 
     GreedyArgs a{prob_dev, Hp, Wp, crop_y, crop_x, H, W, border, conf_thresh, dist_thresh, B, ntx, nty,
                  reinterpret_cast<u64 *>(w + l.off_alive), reinterpret_cast<u64 *>(w + l.off_kept),
-                 reinterpret_cast<int *>(w + l.off_dead), reinterpret_cast<int *>(w + l.off_list),
+                 reinterpret_cast<int *>(w + l.off_dead), reinterpret_cast<int *>(w + l.off_chg),
+                 reinterpret_cast<int *>(w + l.off_keptr), reinterpret_cast<int *>(w + l.off_list),
                  reinterpret_cast<int *>(w + l.off_dlist), reinterpret_cast<int *>(w),
                  reinterpret_cast<int2 *>(w + l.off_surv), reinterpret_cast<int *>(w + l.off_counts), total_dev};
     // (fill kernels, not hipMemsetAsync: see balf_fill_u32 in common.h)
     if (balf_fill_u32(w, 0u, l.zero_bytes / 4, st) != BALF_OK) return BALF_ERR_LAUNCH;
     if (balf_fill_u32(w + l.off_dead, (unsigned)ALIVE_FOREVER, l.dead_bytes / 4, st) != BALF_OK) return BALF_ERR_LAUNCH;
 
-    constexpr int keep_lds = (int)sizeof(KeepLds), tail_lds = (int)(sizeof(KeepLds) + sizeof(KillLds));
+    constexpr int keep_lds = (int)sizeof(KeepLds), tail_lds = (int)(sizeof(KeepLds) + sizeof(KillLds) + sizeof(TailLds));
     static_assert(sizeof(KeepLds) % 16 == 0 && 2 * sizeof(KeepLds) <= 160 * 1024, "two window-mode workgroups per CU");
     if (!allow_lds<greedy_keep_first_kernel>(keep_lds) || !allow_lds<greedy_keep_window_kernel>(keep_lds) ||
         !allow_lds<greedy_tail_kernel>(tail_lds))
