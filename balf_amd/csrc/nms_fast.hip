@@ -30,8 +30,8 @@
 //     always enqueued (12); a launch whose image list is empty returns at once.  What is still alive after them is finished by
 //     greedy_tail_kernel: ONE workgroup per image looping rounds over its own list until the list is empty -- images are
 //     independent, so no workgroup ever waits for another one and every wave reaches its exit.  The adversarial inputs (a
-//     1080p monotone ramp or constant plateau: ~120-190 rounds with a wavefront of kept points) take 0.2 s there instead
-//     of 1.3 ms, exact like everything else (tools/greedy_ramp_probe.py).
+//     1080p monotone ramp or constant plateau: ~120-190 rounds with a wavefront of kept points) take 0.2 s there (1.6 s
+//     without the skip, BALF_GREEDY_NOSKIP=1) instead of 1.3 ms, exact like everything else (tools/greedy_ramp_probe.py).
 // Then the top-K / sort kernel of nms_topk.hip and the optional sub-pixel soft-argmax.
 #include <stdlib.h>
 
@@ -65,6 +65,7 @@ struct GreedyArgs {
     float conf;
     int d;                        // dist_thresh
     int B, ntx, nty;              // tiles per row / column; 64-bit words per bit-map row = ntx
+    int noskip;                   // BALF_GREEDY_NOSKIP=1 (A/B switch, development aid): every pass visits every listed tile
     u64 *alive;                   // [B, H, ntx]
     u64 *kept;                    // [B, H, ntx] kept in the current round
     int *dead_round;              // [B, nty * ntx]
@@ -179,7 +180,7 @@ __device__ __forceinline__ bool tile_dead(const GreedyArgs &a, int b, int tyi, i
 // round r: kept_round == r -- no newly kept point in reach, nothing dies.  On a monotone ramp or a plateau (one wavefront of
 // kept points moving one window per round, ~W/d rounds) all but the tiles on the front skip.  Every thread evaluates it alike.
 __device__ __forceinline__ bool nbr_round_is(const GreedyArgs &a, const int *arr, int b, int tyi, int txi, int value) {
-    bool hit = false;
+    bool hit = a.noskip != 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int y = tyi - 1 + k / 3, x = txi - 1 + k % 3;
@@ -191,7 +192,7 @@ __device__ __forceinline__ bool nbr_round_is(const GreedyArgs &a, const int *arr
 // the same for a workgroup that is ONE wave (pairwise keep, kill kernels): lanes 0..8 look at one neighbour each
 __device__ __forceinline__ bool nbr_round_is_wave(const GreedyArgs &a, const int *arr, int b, int tyi, int txi, int value) {
     const int lane = threadIdx.x;
-    bool hit = false;
+    bool hit = a.noskip != 0;
     if (lane < 9) {
         const int y = tyi - 1 + lane / 3, x = txi - 1 + lane % 3;
         if (y >= 0 && y < a.nty && x >= 0 && x < a.ntx) hit = arr[((long)b * a.nty + y) * a.ntx + x] == value;
@@ -783,6 +784,7 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
     const int ntx = balf_ceil_div(W, TW), nty = balf_ceil_div(H, TH), tiles = ntx * nty;
 
     GreedyArgs a{prob_dev, Hp, Wp, crop_y, crop_x, H, W, border, conf_thresh, dist_thresh, B, ntx, nty,
+                 getenv("BALF_GREEDY_NOSKIP") != nullptr,
                  reinterpret_cast<u64 *>(w + l.off_alive), reinterpret_cast<u64 *>(w + l.off_kept),
                  reinterpret_cast<int *>(w + l.off_dead), reinterpret_cast<int *>(w + l.off_chg),
                  reinterpret_cast<int *>(w + l.off_keptr), reinterpret_cast<int *>(w + l.off_list),
