@@ -351,6 +351,10 @@ def stub_main(args, json_fd):
     dt_max, dt_min = float(t[0]), -float(t[1])
     n_all = total if total is not None else world * b
     assert out[0].shape == (n_all, k) and torch.equal(out[0][lo:lo + b], idx)
+    # what a real rank binds: cuda:LOCAL_RANK (main() does torch.cuda.set_device(local_rank)); the stub has no GPU and only reports it
+    rank_devices = [None] * world
+    dist.all_gather_object(rank_devices, {"rank": rank, "local_rank_env": int(os.environ.get("LOCAL_RANK", "0")),
+                                          "would_bind": f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}", "images": [lo, lo + b]})
     if rank == 0:
         b = n_all / world                      # (mean images per rank, for the line below)
         res = {"metric": "bench.py launcher plumbing (stub step: no detector, no GPU)", "stub": True,
@@ -362,6 +366,7 @@ def stub_main(args, json_fd):
                "config": {"workload": f"stub: {b} x {k} fake keypoints per rank, all-gather only", "global_batch": n_all,
                           "parallelism": f"dp{world}"},
                "launched_by": "bench.py" if os.environ.get("BALF_BENCH_LAUNCHED") else "external launcher",
+               "rank_devices": rank_devices,
                "rank_env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}}
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     dist.barrier()

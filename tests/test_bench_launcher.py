@@ -48,6 +48,10 @@ def test_plain_gpus8_starts_eight_ranks():
     res = _one_line(r.stdout)
     assert res["n_gpus"] == 8 and res["rccl_ranks"] == 8 and res["config"]["global_batch"] == 32
     assert res["config"]["parallelism"] == "dp8" and res["scaling"] == "weak"
+    # every rank got its own LOCAL_RANK (the device it binds on a real node) and its own contiguous shard of the batch
+    devs = res["rank_devices"]
+    assert [d["rank"] for d in devs] == list(range(8)) and [d["would_bind"] for d in devs] == [f"cuda:{r}" for r in range(8)]
+    assert [d["images"] for d in devs] == [[4 * r, 4 * r + 4] for r in range(8)]
 
 
 def test_torchrun_form_gives_the_same_line():
