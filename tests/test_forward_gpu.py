@@ -456,6 +456,7 @@ def test_lazy_guard_attributes_the_flag_to_its_call_and_holds_no_tensor(monkeypa
     first = m._guard[torch.device("cuda:0")].seq
     with W.catch_warnings():
         W.simplefilter("error")
+        torch.cuda._sleep(int(4e8))                      # the stream is busy (~0.2 s): all three calls are enqueued before any finishes
         out_a = m(xb, want_logits=False)
         out_b = m(calm, want_logits=False)
         out_c = m(calm, want_logits=False)
