@@ -86,7 +86,9 @@ class GraphedDetector:
             x[:, :, top:top + h, left:left + w] = rgb.permute(0, 3, 1, 2).float() / 255.0
             model.validate_fp16(x)                            # raises if the split path leaves its range on the example
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # thread_local: only this thread must keep to capturable calls (it does: no entry point of the library synchronises or
+        # queries); another thread polling an event -- torch's NCCL watchdog does -- would invalidate a "global" capture
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             self._out = detect_batch_u8(model, self._in, *self._args)
 
     def __call__(self, images_u8: torch.Tensor):

@@ -412,7 +412,9 @@ def single_image_latency(model, dev, h, w, k, calls=60):
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # (thread_local: the NCCL watchdog thread of the single-rank group polls its events meanwhile; in the default "global" mode
+        # an event query from ANY thread invalidates a capture)
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             g_out = pipeline.detect_batch_u8(model, img, 15, 15, k)
         gw = []
         for _ in range(calls):
