@@ -108,8 +108,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // The w-R+1 inputs common to all R windows are reduced once; each output adds a running maximum from the left
 // remainder and one from the right remainder: ~(w + 3R) max operations for R outputs instead of R (w - 1).
 // +0 means "dead" and is the identity.
-template <int R, typename In, typename Out>
-__device__ __forceinline__ void window_max_run(int w, In in, Out out) {
+template <int R, int WC = 0, typename In, typename Out>
+__device__ __forceinline__ void window_max_run(int w_runtime, In in, Out out) {
+    const int w = WC > 0 ? WC : w_runtime;           // WC > 0: the window is a compile-time constant (every loop below unrolls)
     if (w >= R) {
         // the reads of a batch are independent (issued together, one wait): with two waves per SIMD a read-max-read chain
         // of 30 LDS round trips per item was the whole kernel
@@ -119,13 +120,22 @@ __device__ __forceinline__ void window_max_run(int w, In in, Out out) {
 #pragma unroll
         for (int j = 1; j < R; ++j) right[j] = in(w - 1 + j);
         double core = in(R - 1);
-        int k = R;
-        for (; k + 8 <= w; k += 8) {
+        if constexpr (WC > 0) {                       // compile-time window: straight-line code, immediate LDS offsets
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = in(k + u);
-            core = kmax(core, kmax(kmax(kmax(t[0], t[1]), kmax(t[2], t[3])), kmax(kmax(t[4], t[5]), kmax(t[6], t[7]))));
+            for (int k0 = R; k0 < WC; k0 += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = k0 + u < WC ? in(k0 + u) : 0.0;
+                core = kmax(core, kmax(kmax(kmax(t[0], t[1]), kmax(t[2], t[3])), kmax(kmax(t[4], t[5]), kmax(t[6], t[7]))));
+            }
+        } else {
+            int k = R;
+            for (; k + 8 <= w; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = in(k + u);
+                core = kmax(core, kmax(kmax(kmax(t[0], t[1]), kmax(t[2], t[3])), kmax(kmax(t[4], t[5]), kmax(t[6], t[7]))));
+            }
+            for (; k < w; ++k) core = kmax(core, in(k));
         }
-        for (; k < w; ++k) core = kmax(core, in(k));
         double acc = 0.0;
 #pragma unroll
         for (int j = R - 2; j >= 0; --j) { acc = kmax(acc, left[j]); left[j] = acc; }
@@ -202,22 +212,23 @@ __device__ __forceinline__ bool nbr_round_is_wave(const GreedyArgs &a, const int
 
 // The two window passes over the keys in s.in (tile + d halo) and the kept / alive bits of the tile's rows into s.kbits /
 // s.abits (zeroed by the caller before the barrier this begins with).
-template <bool FIRST>
+template <bool FIRST, int DC = -1>
 __device__ __forceinline__ void window_passes(const GreedyArgs &a, KeepLds &s, int tyi, int txi) {
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int d = a.d, w = 2 * d + 1, RW = TW + 2 * d;
+    const int d = DC >= 0 ? DC : a.d, w = 2 * d + 1, RW = TW + 2 * d;      // DC >= 0: dist_thresh known at compile time
+    constexpr int WC = DC >= 0 ? 2 * DC + 1 : 0;
     lds_barrier();
     for (int i = tid; i < RW * (TH / 8); i += nthr) {                      // column pass: 8 outputs per item, lanes along x
         const int blk = i / RW, c = i - blk * RW, r0 = blk * 8;
         const double *col = s.in + r0 * RS + c;
-        window_max_run<8>(w, [&](int k) { return col[k * RS]; }, [&](int j, double v) { s.col[(r0 + j) * RS + c] = v; });
+        window_max_run<8, WC>(w, [&](int k) { return col[k * RS]; }, [&](int j, double v) { s.col[(r0 + j) * RS + c] = v; });
     }
     lds_barrier();
     for (int i = tid; i < TH * (TW / 8); i += nthr) {                      // row pass: 8 outputs per item, lanes along y
         const int r = i & (TH - 1), blk = i / TH, c0 = blk * 8;
         const double *row = s.col + r * RS + c0;
         unsigned keep8 = 0, alive8 = 0;
-        window_max_run<8>(w, [&](int k) { return row[k]; }, [&](int j, double m) {
+        window_max_run<8, WC>(w, [&](int k) { return row[k]; }, [&](int j, double m) {
             const double own = s.in[(r + d) * RS + c0 + j + d];
             if (own != 0.0) {
                 alive8 |= 1u << j;
@@ -541,6 +552,7 @@ __device__ __forceinline__ void first_fetch(const GreedyArgs &a, int g, float (&
     }
 }
 
+template <int DC>     // DC = 15: the demo's dist_thresh with every window loop unrolled and its index arithmetic folded; -1: any distance
 __global__ __launch_bounds__(KTHREADS) void greedy_keep_first_kernel(GreedyArgs a, int total, int per) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KeepLds &s = *reinterpret_cast<KeepLds *>(smem);
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(KTHREADS) void greedy_keep_first_kernel(GreedyArgs 
     const int run = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int g0 = run * per, g1 = g0 + per < total ? g0 + per : total;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tiles = a.nty * a.ntx, d = a.d, RH = TH + 2 * d, RW = TW + 2 * d;
+    const int tiles = a.nty * a.ntx, d = DC >= 0 ? DC : a.d, RH = TH + 2 * d, RW = TW + 2 * d;
     float v[FROWS][2];
     if (g0 < g1) first_fetch(a, g0, v);
     for (int g = g0; g < g1; ++g) {
@@ -567,7 +579,7 @@ __global__ __launch_bounds__(KTHREADS) void greedy_keep_first_kernel(GreedyArgs 
             }
         }
         if (g + 1 < g1) first_fetch(a, g + 1, v);     // in flight during the passes
-        window_passes<true>(a, s, tyi, txi);
+        window_passes<true, DC>(a, s, tyi, txi);
         lds_barrier();
         if (tid < 64) {
             u64 kw = 0ull;
@@ -796,7 +808,8 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
 
     constexpr int keep_lds = (int)sizeof(KeepLds), tail_lds = (int)(sizeof(KeepLds) + sizeof(KillLds) + sizeof(TailLds));
     static_assert(sizeof(KeepLds) % 16 == 0 && 2 * sizeof(KeepLds) <= 160 * 1024, "two window-mode workgroups per CU");
-    if (!allow_lds<greedy_keep_first_kernel>(keep_lds) || !allow_lds<greedy_keep_window_kernel>(keep_lds) ||
+    if (!allow_lds<greedy_keep_first_kernel<15>>(keep_lds) || !allow_lds<greedy_keep_first_kernel<-1>>(keep_lds) ||
+        !allow_lds<greedy_keep_window_kernel>(keep_lds) ||
         !allow_lds<greedy_tail_kernel>(tail_lds))
         return BALF_ERR_LAUNCH;
     // round 1 over every tile; rounds 2.. over the lists: launches sized for a full list that return at once on an empty one
@@ -805,8 +818,12 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
     const int gw = tiles < 512 / B + 16 ? tiles : 512 / B + 16;
     const int total = tiles * B;
     const int first_wg = total < FIRST_WG ? (total + 7) / 8 * 8 : FIRST_WG, per = (total + first_wg - 1) / first_wg;
-    BALF_PROF(balf_prof::kGreedyKeep, st,
-              hipLaunchKernelGGL(greedy_keep_first_kernel, dim3(first_wg), dim3(KTHREADS), keep_lds, st, a, total, per));
+    if (dist_thresh == 15)
+        BALF_PROF(balf_prof::kGreedyKeep, st,
+                  hipLaunchKernelGGL(greedy_keep_first_kernel<15>, dim3(first_wg), dim3(KTHREADS), keep_lds, st, a, total, per));
+    else
+        BALF_PROF(balf_prof::kGreedyKeep, st,
+                  hipLaunchKernelGGL(greedy_keep_first_kernel<-1>, dim3(first_wg), dim3(KTHREADS), keep_lds, st, a, total, per));
     BALF_PROF(balf_prof::kGreedyKill, st,
               hipLaunchKernelGGL(greedy_kill_kernel<true>, dim3(tiles, B), dim3(LTHREADS), 0, st, a, 1));
     BALF_LAUNCH_CHECK();
