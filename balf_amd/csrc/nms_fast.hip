@@ -529,7 +529,11 @@ __device__ void keep_tile_sparse(const GreedyArgs &a, SparseLds &s, int b, int t
 // spent a third of the pass being launched), and the next tile's score values are requested into registers before the
 // two window passes of the current one, so that the HBM round trip runs under them (it was half of the pass).
 constexpr int FIRST_WG = 512;
-constexpr int FROWS = RH_MAX / (KTHREADS / 64);          // region rows per wave: 16
+#ifndef BALF_GREEDY_FT
+#define BALF_GREEDY_FT 512      // (256: 0.88 ms of keep passes per 32 x 1080p, 512: 0.79 -- four waves per SIMD hide the LDS round trips of the window passes)
+#endif
+constexpr int FTHREADS = BALF_GREEDY_FT;                 // threads of the round-1 workgroup
+constexpr int FROWS = RH_MAX / (FTHREADS / 64);          // region rows per wave
 
 // wave wv holds region rows wv, wv + 4, ..., lanes along x (columns lane and lane + 64): coalesced, no index division
 __device__ __forceinline__ void first_fetch(const GreedyArgs &a, int g, float (&v)[FROWS][2]) {
@@ -541,7 +545,7 @@ __device__ __forceinline__ void first_fetch(const GreedyArgs &a, int g, float (&
     const float *img = a.src + (long)b * a.Hs * a.Ws + (long)a.crop_y * a.Ws + a.crop_x;
 #pragma unroll
     for (int k = 0; k < FROWS; ++k) {
-        const int r = wv + (KTHREADS / 64) * k, y = ry0 + r;
+        const int r = wv + (FTHREADS / 64) * k, y = ry0 + r;
         const bool yok = r < RH && y >= lo_y && y < hi_y;
         const float *rowp = img + (long)y * a.Ws;
 #pragma unroll
@@ -553,7 +557,7 @@ __device__ __forceinline__ void first_fetch(const GreedyArgs &a, int g, float (&
 }
 
 template <int DC>     // DC = 15: the demo's dist_thresh with every window loop unrolled and its index arithmetic folded; -1: any distance
-__global__ __launch_bounds__(KTHREADS) void greedy_keep_first_kernel(GreedyArgs a, int total, int per) {
+__global__ __launch_bounds__(FTHREADS) void greedy_keep_first_kernel(GreedyArgs a, int total, int per) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KeepLds &s = *reinterpret_cast<KeepLds *>(smem);
     // consecutive workgroups go to different XCDs (8 L2s): workgroup i takes run (i % 8) * (n / 8) + i / 8, so that each XCD
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(KTHREADS) void greedy_keep_first_kernel(GreedyArgs 
         if (tid < TH * 2) { s.kbits[tid] = 0u; s.abits[tid] = 0u; }
 #pragma unroll
         for (int k = 0; k < FROWS; ++k) {
-            const int r = wv + (KTHREADS / 64) * k;
+            const int r = wv + (FTHREADS / 64) * k;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int c = lane + 64 * h;
@@ -820,10 +824,10 @@ extern "C" int balf_greedy_nms(const float *prob_dev, int B, int Hp, int Wp, int
     const int first_wg = total < FIRST_WG ? (total + 7) / 8 * 8 : FIRST_WG, per = (total + first_wg - 1) / first_wg;
     if (dist_thresh == 15)
         BALF_PROF(balf_prof::kGreedyKeep, st,
-                  hipLaunchKernelGGL(greedy_keep_first_kernel<15>, dim3(first_wg), dim3(KTHREADS), keep_lds, st, a, total, per));
+                  hipLaunchKernelGGL(greedy_keep_first_kernel<15>, dim3(first_wg), dim3(FTHREADS), keep_lds, st, a, total, per));
     else
         BALF_PROF(balf_prof::kGreedyKeep, st,
-                  hipLaunchKernelGGL(greedy_keep_first_kernel<-1>, dim3(first_wg), dim3(KTHREADS), keep_lds, st, a, total, per));
+                  hipLaunchKernelGGL(greedy_keep_first_kernel<-1>, dim3(first_wg), dim3(FTHREADS), keep_lds, st, a, total, per));
     BALF_PROF(balf_prof::kGreedyKill, st,
               hipLaunchKernelGGL(greedy_kill_kernel<true>, dim3(tiles, B), dim3(LTHREADS), 0, st, a, 1));
     BALF_LAUNCH_CHECK();
