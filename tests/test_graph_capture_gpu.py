@@ -65,3 +65,13 @@ def test_graphed_detector_matches_eager_calls():
             assert torch.equal(a, b)
     with pytest.raises(ValueError):
         det(imgs[0][:2])
+    # RGB input [B,H,W,3]
+    rgb = [torch.from_numpy(np.stack([np.stack([synth.synthetic_gray_u8(h, w, 5 * j + i + c) for c in range(3)], axis=-1) for i in range(2)])).to(DEV)
+           for j in range(2)]
+    det3 = pipeline.GraphedDetector(m, rgb[0], 15, 15, k)
+    for x in (rgb[1], rgb[0]):
+        got = [t.clone() for t in det3(x)]
+        want = pipeline.detect_batch_u8(m, x, 15, 15, k)
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
